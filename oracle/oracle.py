@@ -1,0 +1,179 @@
+"""ctypes front-end for the CPU oracle (oracle/vnl_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force: bool = False) -> None:
+    """Compile both precisions of the oracle with the committed Makefile."""
+    outs = [os.path.join(_HERE, "_build", f"liborc_{p}.so") for p in ("f64", "f32")]
+    src = os.path.join(_HERE, "vnl_oracle.c")
+    stale = force or any(not os.path.exists(o) or os.path.getmtime(o) < os.path.getmtime(src) for o in outs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+class EnvSpec(C.Structure):
+    _fields_ = [
+        ("T", C.c_int),
+        ("ref_len", C.c_int),
+        ("sub_clip_length", C.c_int),
+        ("n_frames", C.c_int),
+        ("nb", C.c_int),
+        ("nee", C.c_int),
+        ("napp", C.c_int),
+        ("njc", C.c_int),
+        ("body_idxs", C.c_int * 64),
+        ("end_eff_idx", C.c_int * 8),
+        ("app_body", C.c_int * 8),
+        ("app_ref_col", C.c_int * 8),
+        ("com_ref_col", C.c_int),
+        ("joint_cols", C.c_int * 128),
+        ("healthy_z_lo", C.c_double),
+        ("healthy_z_hi", C.c_double),
+        ("termination_threshold", C.c_double),
+        ("body_error_multiplier", C.c_double),
+    ]
+
+
+class _Clip(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in
+                ("position", "quaternion", "joints", "body_positions", "velocity", "angular_velocity",
+                 "joints_velocity")]
+
+
+_STATE_F = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xmat1", "com1", "qfrc_actuator", "obs", "traj",
+            "reward", "done", "metrics")
+
+
+class _State(C.Structure):
+    _fields_ = ([(n, C.POINTER(C.c_float)) for n in _STATE_F]
+                + [("cur_frame", C.POINTER(C.c_int32)), ("sub_clip_frame", C.POINTER(C.c_int32)),
+                   ("termination_error", C.POINTER(C.c_float))])
+
+
+def make_envspec(spec: dict) -> EnvSpec:
+    """spec: the dict produced by vnl_brax_imitation_amd.envs.rodent.RodentTracking.env_spec()."""
+    e = EnvSpec()
+    for k in ("T", "ref_len", "sub_clip_length", "n_frames", "nb", "nee", "napp", "njc", "com_ref_col"):
+        setattr(e, k, int(spec[k]))
+    for k in ("healthy_z_lo", "healthy_z_hi", "termination_threshold", "body_error_multiplier"):
+        setattr(e, k, float(spec[k]))
+    for k in ("body_idxs", "end_eff_idx", "app_body", "app_ref_col", "joint_cols"):
+        arr = getattr(e, k)
+        for i, v in enumerate(spec[k]):
+            arr[i] = int(v)
+    return e
+
+
+class Oracle:
+    """One compiled model + (optionally) one clip; per-stage and batched env entry points."""
+
+    def __init__(self, blob: bytes, precision: str = "f64"):
+        build()
+        self.lib = C.CDLL(os.path.join(_HERE, "_build", f"liborc_{precision}.so"))
+        self.real = np.float64 if precision == "f64" else np.float32
+        self._creal = C.c_double if precision == "f64" else C.c_float
+        L = self.lib
+        L.orc_model_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.orc_data_create.restype = C.c_void_p
+        L.orc_data_create.argtypes = [C.c_void_p]
+        L.orc_data_destroy.argtypes = [C.c_void_p]
+        L.orc_data_field.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(self._creal)),
+                                     C.POINTER(C.c_int)]
+        L.orc_solver_niter.argtypes = [C.c_void_p]
+        for fn in ("kinematics", "com_pos", "crb", "factor_m", "collision", "make_constraint", "com_vel", "passive",
+                   "rne", "actuation", "acceleration", "solve", "forward", "euler", "step"):
+            getattr(L, "orc_" + fn).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(L, "orc_" + fn).restype = None
+        L.orc_env_reset.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
+                                    C.c_void_p, C.POINTER(_State)]
+        L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
+                                   C.POINTER(_State)]
+        assert L.orc_envspec_size() == C.sizeof(EnvSpec)
+        self._blob = C.create_string_buffer(blob, len(blob))
+        h = C.c_void_p()
+        if L.orc_model_create(self._blob, len(blob), C.byref(h)) != 0:
+            raise RuntimeError("orc_model_create failed")
+        self.model = h
+        self.data = C.c_void_p(L.orc_data_create(self.model))
+
+    # ---- single-env, per-stage access ---------------------------------------
+    def field(self, name: str) -> np.ndarray:
+        """Writable numpy view of a named orc_data array."""
+        p = C.POINTER(self._creal)()
+        n = C.c_int()
+        if self.lib.orc_data_field(self.model, self.data, name.encode(), C.byref(p), C.byref(n)) != 0:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def set(self, **kw) -> None:
+        for k, v in kw.items():
+            self.field(k)[:] = np.asarray(v, dtype=self.real).ravel()
+
+    def call(self, stage: str) -> None:
+        getattr(self.lib, "orc_" + stage)(self.model, self.data)
+
+    @property
+    def solver_niter(self) -> int:
+        return self.lib.orc_solver_niter(self.data)
+
+    # ---- batched env ------------------------------------------------------
+    def bind_env(self, spec: dict, clip: dict, nbody: int, nq: int, nv: int, nu: int) -> None:
+        self.spec = make_envspec(spec)
+        self._dims = dict(nbody=nbody, nq=nq, nv=nv, nu=nu)
+        self._clip_arrays = {k: np.ascontiguousarray(clip[k], dtype=np.float32) for k in
+                             ("position", "quaternion", "joints", "body_positions", "velocity", "angular_velocity",
+                              "joints_velocity")}
+        self._clip = _Clip(*[self._clip_arrays[k].ctypes.data_as(C.POINTER(C.c_float)) for k, _ in _Clip._fields_])
+        s = self.spec
+        self.obs_size = nq + 2 * nv + 3 * s.nee
+        self.traj_size = s.ref_len * (3 * s.napp + 6 * s.nb + 3 + s.njc)
+
+    def new_state(self, B: int) -> dict:
+        d = self._dims
+        shp = dict(qpos=d["nq"], qvel=d["nv"], act=d["nu"], qacc_warmstart=d["nv"], xpos=3 * d["nbody"], xmat1=9,
+                   com1=3, qfrc_actuator=d["nv"], obs=self.obs_size, traj=self.traj_size, reward=0, done=0,
+                   metrics=7)
+        st = {k: np.zeros((B, n) if n else (B,), dtype=np.float32) for k, n in shp.items()}
+        st["cur_frame"] = np.zeros(B, dtype=np.int32)
+        st["sub_clip_frame"] = np.zeros(B, dtype=np.int32)
+        st["termination_error"] = np.zeros(B, dtype=np.float32)
+        return st
+
+    def _cstate(self, st: dict) -> _State:
+        args = [st[k].ctypes.data_as(C.POINTER(C.c_float)) for k in _STATE_F]
+        args += [st["cur_frame"].ctypes.data_as(C.POINTER(C.c_int32)),
+                 st["sub_clip_frame"].ctypes.data_as(C.POINTER(C.c_int32)),
+                 st["termination_error"].ctypes.data_as(C.POINTER(C.c_float))]
+        return _State(*args)
+
+    def env_reset(self, start_frame: np.ndarray, noise: np.ndarray) -> dict:
+        B = len(start_frame)
+        st = self.new_state(B)
+        sf = np.ascontiguousarray(start_frame, dtype=np.int32)
+        nz = np.ascontiguousarray(noise, dtype=np.float32)
+        cs = self._cstate(st)
+        rc = self.lib.orc_env_reset(self.model, C.byref(self.spec), C.byref(self._clip), B, sf.ctypes.data,
+                                    nz.ctypes.data, C.byref(cs))
+        assert rc == 0
+        return st
+
+    def env_step(self, st: dict, action: np.ndarray) -> dict:
+        """In-place on `st` (like the product's step); returns st for convenience."""
+        B = st["qpos"].shape[0]
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        cs = self._cstate(st)
+        rc = self.lib.orc_env_step(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data, C.byref(cs))
+        assert rc == 0
+        return st
