@@ -1,0 +1,164 @@
+/*
+ * vnl.h -- C-ABI of the MI355X-native rodent-imitation rollout.
+ *
+ * The reference (talmolab/VNL-Brax-Imitation) is pure Python on JAX/MJX/Brax and
+ * has no FFI of its own; this ABI is the boundary a maintainer binds (ctypes, see
+ * INTEGRATION.md) to replace, for the hot path only:
+ *
+ *   vnl_env_reset  <->  RodentTracking.reset          reference envs/rodent.py:119-176
+ *                       (+ brax PipelineEnv.pipeline_init = mjx.forward, rodent.py:148)
+ *   vnl_env_step   <->  RodentTracking.step           reference envs/rodent.py:178-239
+ *                       (+ PipelineEnv.pipeline_step = n_frames x mjx.step, rodent.py:181)
+ *   vnl_policy_*   <->  make_inference_fn(...).policy reference ppo_imitation/ppo_networks.py:45-83
+ *                       IntentionNetwork.__call__     reference ppo_imitation/intention_policy_network.py:91-105
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every state / observation / action buffer is CALLER-OWNED device memory,
+ *     float32 (int32 for frame counters), laid out structure-of-arrays
+ *     [feature][env] with env stride = num_envs (lane e of a wavefront touches
+ *     element feature*num_envs + e: one coalesced 256-B line per wave access);
+ *   - the library owns model constants, the clip copy and per-env scratch,
+ *     released by vnl_env_destroy / vnl_model_destroy;
+ *   - all work is enqueued asynchronously on the caller's HIP stream (passed as
+ *     void* = hipStream_t); no hidden synchronisation; a handle is not
+ *     thread-safe (one handle per GPU / process);
+ *   - return 0 on success, negative error code otherwise; message through
+ *     vnl_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with VNL_ERR_NO_DEVICE.
+ */
+#ifndef VNL_H_
+#define VNL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNL_OK 0
+#define VNL_ERR_ARG -1
+#define VNL_ERR_BLOB -2
+#define VNL_ERR_HIP -3
+#define VNL_ERR_NO_DEVICE -4
+#define VNL_ERR_UNSUPPORTED -5
+
+typedef struct vnl_model vnl_model;
+typedef struct vnl_env vnl_env;
+typedef struct vnl_policy vnl_policy;
+
+/* Environment description: mirrors the constructor state of RodentTracking
+ * (reference envs/rodent.py:17-117).  Index arrays are the EFFECTIVE indices
+ * after the reference's (buggy) use of MuJoCo ids on filtered clip axes and
+ * JAX's clamp-on-gather semantics; the Python
+ * mirror derives them from names exactly as the reference does. */
+typedef struct vnl_envspec {
+  int32_t clip_frames;     /* T: frames per clip */
+  int32_t num_clips;       /* C: clips resident (1 for the single-clip env) */
+  int32_t ref_traj_length; /* rodent.py:34 */
+  int32_t sub_clip_length; /* rodent.py:33 */
+  int32_t n_frames;        /* physics substeps per control step, rodent.py:97-99 */
+  int32_t num_track_bodies;/* width of the filtered clip.body_positions, rodent.py:113-115 */
+  int32_t num_end_eff;
+  int32_t num_appendages;
+  int32_t num_joint_cols;
+  int32_t com_ref_col;
+  const int32_t* body_idxs;   /* [num_track_bodies] model body ids, rodent.py:80-85 */
+  const int32_t* end_eff_idx; /* [num_end_eff] model body ids, rodent.py:65-70 */
+  const int32_t* app_body;    /* [num_appendages] model body ids, rodent.py:71-76,307 */
+  const int32_t* app_ref_col; /* [num_appendages] clamped columns of the filtered clip axis */
+  const int32_t* joint_cols;  /* [num_joint_cols] clamped columns of the (nq-7)-wide joint axis */
+  float healthy_z_lo, healthy_z_hi; /* rodent.py:31 */
+  float termination_threshold;      /* rodent.py:35 */
+  float body_error_multiplier;      /* rodent.py:36 */
+  /* clip tensors, HOST pointers, float32, row-major (C, T, n); copied at create.
+   * Fields of ReferenceClip, reference preprocessing/mjx_preprocess.py:21-40. */
+  const float* position;         /* (C,T,3) */
+  const float* quaternion;       /* (C,T,4) */
+  const float* joints;           /* (C,T,nq-7) */
+  const float* body_positions;   /* (C,T,num_track_bodies,3), already filtered */
+  const float* velocity;         /* (C,T,3) */
+  const float* angular_velocity; /* (C,T,3) */
+  const float* joints_velocity;  /* (C,T,nq-7) */
+} vnl_envspec;
+
+/* Caller-owned device buffers, SoA [feature][num_envs]. */
+typedef struct vnl_state {
+  /* brax State.pipeline_state (mjx.Data) -- carried */
+  float* qpos;           /* [nq] */
+  float* qvel;           /* [nv] */
+  float* act;            /* [nu] */
+  float* qacc_warmstart; /* [nv] */
+  /* derived by the last mjx.forward (lag qpos by one substep) */
+  float* xpos;           /* [3*nbody] */
+  float* xquat;          /* [4*nbody] */
+  float* subtree_com1;   /* [3]  = data.subtree_com[1] */
+  float* qfrc_actuator;  /* [nv] */
+  /* brax State.{obs,reward,done,metrics} */
+  float* obs;     /* [obs_size]  */
+  float* reward;  /* [1] */
+  float* done;    /* [1] */
+  float* metrics; /* [7]: rcom rvel rtrunk rquat ract rapp termination_error */
+  /* brax State.info */
+  float* traj;              /* [traj_size] */
+  float* termination_error; /* [1] */
+  int32_t* cur_frame;       /* [1] */
+  int32_t* sub_clip_frame;  /* [1] */
+  int32_t* clip_id;         /* [1] which resident clip this env tracks (0 for single clip) */
+} vnl_state;
+
+/* Model dimensions, for sizing caller buffers. */
+typedef struct vnl_dims {
+  int32_t nq, nv, nu, nbody, njnt, ngeom_collide, ncon, nefc, obs_size, traj_size;
+  int32_t workspace_floats_per_env;
+} vnl_dims;
+
+const char* vnl_last_error(void);
+int vnl_version(void);
+
+/* model: blob produced by vnl_brax_imitation_amd.model.blob.to_blob (host memory) */
+int vnl_model_create(const void* blob, size_t nbytes, vnl_model** out);
+void vnl_model_destroy(vnl_model*);
+
+/* env: device = HIP ordinal (>= 0) */
+int vnl_env_create(const vnl_model*, const vnl_envspec*, int32_t num_envs, int32_t device, vnl_env** out);
+void vnl_env_destroy(vnl_env*);
+int vnl_env_dims(const vnl_env*, vnl_dims* out);
+
+/* reset: start_frame [num_envs] int32, clip_id written by caller into state->clip_id,
+ * noise SoA [nq][num_envs] (already scaled by reset_noise_scale; rodent.py:131-147). */
+int vnl_env_reset(vnl_env*, const int32_t* start_frame, const float* noise, const vnl_state* state, void* stream);
+
+/* step: action SoA [nu][num_envs]; state updated in place. */
+int vnl_env_step(vnl_env*, const float* action, const vnl_state* state, void* stream);
+
+/* Bisection hook: device pointer + element count (per env) of a named scratch
+ * section as left by the last reset/step ("qM", "qLD", "qfrc_smooth", "qacc_smooth",
+ * "qacc", "efc_D", "efc_aref", "con_dist", ...).  Layout SoA [count][num_envs]. */
+int vnl_env_scratch(const vnl_env*, const char* name, float** dev_ptr, int32_t* count);
+
+/* ---- policy forward (intention network), ppo_networks.py:45-83 ----------------
+ * params: flat float32 device buffer in the order documented in INTEGRATION.md.
+ * Inputs traj/obs SoA as produced by vnl_env_step; normaliser mean/std [obs_size].
+ * eps_latent [latent][B] and eps_action [act][B] are caller-supplied N(0,1) draws
+ * (the JAX threefry stream is not reproduced).  Outputs SoA. */
+typedef struct vnl_policy_spec {
+  int32_t traj_size, obs_size, action_size, latent_size;
+  int32_t num_encoder_layers, num_decoder_layers;
+  int32_t encoder_layers[8], decoder_layers[8];
+} vnl_policy_spec;
+
+int vnl_policy_create(const vnl_policy_spec*, int32_t max_batch, int32_t device, vnl_policy** out);
+void vnl_policy_destroy(vnl_policy*);
+int64_t vnl_policy_num_params(const vnl_policy*);
+int vnl_policy_forward(vnl_policy*, const float* params, const float* obs_mean, const float* obs_std,
+                       const float* traj, const float* obs, const float* eps_latent, const float* eps_action,
+                       int32_t batch, int32_t deterministic, float* action, float* raw_action, float* log_prob,
+                       float* logits, float* latent_mean, float* latent_logvar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNL_H_ */

@@ -57,9 +57,8 @@ _STATE_F = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xmat1", "com1", "q
 
 
 class _State(C.Structure):
-    _fields_ = ([(n, C.POINTER(C.c_float)) for n in _STATE_F]
-                + [("cur_frame", C.POINTER(C.c_int32)), ("sub_clip_frame", C.POINTER(C.c_int32)),
-                   ("termination_error", C.POINTER(C.c_float))])
+    _fields_ = ([(n, C.c_void_p) for n in _STATE_F]
+                + [("cur_frame", C.c_void_p), ("sub_clip_frame", C.c_void_p), ("termination_error", C.c_void_p)])
 
 
 def make_envspec(spec: dict) -> EnvSpec:
@@ -145,24 +144,22 @@ class Oracle:
         shp = dict(qpos=d["nq"], qvel=d["nv"], act=d["nu"], qacc_warmstart=d["nv"], xpos=3 * d["nbody"], xmat1=9,
                    com1=3, qfrc_actuator=d["nv"], obs=self.obs_size, traj=self.traj_size, reward=0, done=0,
                    metrics=7)
-        st = {k: np.zeros((B, n) if n else (B,), dtype=np.float32) for k, n in shp.items()}
+        st = {k: np.zeros((B, n) if n else (B,), dtype=self.real) for k, n in shp.items()}
         st["cur_frame"] = np.zeros(B, dtype=np.int32)
         st["sub_clip_frame"] = np.zeros(B, dtype=np.int32)
-        st["termination_error"] = np.zeros(B, dtype=np.float32)
+        st["termination_error"] = np.zeros(B, dtype=self.real)
         return st
 
     def _cstate(self, st: dict) -> _State:
-        args = [st[k].ctypes.data_as(C.POINTER(C.c_float)) for k in _STATE_F]
-        args += [st["cur_frame"].ctypes.data_as(C.POINTER(C.c_int32)),
-                 st["sub_clip_frame"].ctypes.data_as(C.POINTER(C.c_int32)),
-                 st["termination_error"].ctypes.data_as(C.POINTER(C.c_float))]
+        args = [st[k].ctypes.data for k in _STATE_F]
+        args += [st["cur_frame"].ctypes.data, st["sub_clip_frame"].ctypes.data, st["termination_error"].ctypes.data]
         return _State(*args)
 
     def env_reset(self, start_frame: np.ndarray, noise: np.ndarray) -> dict:
         B = len(start_frame)
         st = self.new_state(B)
         sf = np.ascontiguousarray(start_frame, dtype=np.int32)
-        nz = np.ascontiguousarray(noise, dtype=np.float32)
+        nz = np.ascontiguousarray(noise, dtype=self.real)
         cs = self._cstate(st)
         rc = self.lib.orc_env_reset(self.model, C.byref(self.spec), C.byref(self._clip), B, sf.ctypes.data,
                                     nz.ctypes.data, C.byref(cs))
@@ -172,7 +169,7 @@ class Oracle:
     def env_step(self, st: dict, action: np.ndarray) -> dict:
         """In-place on `st` (like the product's step); returns st for convenience."""
         B = st["qpos"].shape[0]
-        a = np.ascontiguousarray(action, dtype=np.float32)
+        a = np.ascontiguousarray(action, dtype=self.real)
         cs = self._cstate(st)
         rc = self.lib.orc_env_step(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data, C.byref(cs))
         assert rc == 0

@@ -1115,15 +1115,17 @@ static int data_has_nan(const orc_model *m, const orc_data *d) {
 }
 
 /*
- * Batched state, AoS row-major (B, n), float32 at the boundary (as JAX arrays are).
+ * Batched state, AoS row-major (B, n).  Arrays are `real`: float32 in the ORC_F32 build (as
+ * JAX arrays are), float64 in the default build so that step-to-step state carries no
+ * float32 quantisation (the dynamics amplify a 1e-7 perturbation ~1e4x per control step).
  * metrics: rcom rvel rtrunk rquat ract rapp termination_error (rodent.py:158-166)
  */
 typedef struct orc_state {
-  float *qpos, *qvel, *act, *qacc_warmstart; /* carried physics state */
-  float *xpos, *xmat1, *com1, *qfrc_actuator; /* derived, from the last forward */
-  float *obs, *traj, *reward, *done, *metrics;
+  real *qpos, *qvel, *act, *qacc_warmstart; /* carried physics state */
+  real *xpos, *xmat1, *com1, *qfrc_actuator; /* derived, from the last forward */
+  real *obs, *traj, *reward, *done, *metrics;
   int32_t *cur_frame, *sub_clip_frame;
-  float *termination_error;
+  real *termination_error;
 } orc_state;
 
 static void load_state(const orc_model *m, orc_data *d, const orc_state *s, int i) {
@@ -1133,14 +1135,14 @@ static void load_state(const orc_model *m, orc_data *d, const orc_state *s, int 
   for (int k = 0; k < m->nu; k++) d->act[k] = s->act[(size_t)i * m->nu + k];
 }
 static void store_state(const orc_model *m, const orc_data *d, orc_state *s, int i) {
-  for (int k = 0; k < m->nq; k++) s->qpos[(size_t)i * m->nq + k] = (float)d->qpos[k];
-  for (int k = 0; k < m->nv; k++) s->qvel[(size_t)i * m->nv + k] = (float)d->qvel[k];
-  for (int k = 0; k < m->nv; k++) s->qacc_warmstart[(size_t)i * m->nv + k] = (float)d->qacc_warmstart[k];
-  for (int k = 0; k < m->nu; k++) s->act[(size_t)i * m->nu + k] = (float)d->act[k];
-  for (int k = 0; k < 3 * m->nbody; k++) s->xpos[(size_t)i * 3 * m->nbody + k] = (float)d->xpos[k];
-  for (int k = 0; k < 9; k++) s->xmat1[(size_t)i * 9 + k] = (float)d->xmat[9 + k];
-  for (int k = 0; k < 3; k++) s->com1[(size_t)i * 3 + k] = (float)d->subtree_com[3 + k];
-  for (int k = 0; k < m->nv; k++) s->qfrc_actuator[(size_t)i * m->nv + k] = (float)d->qfrc_actuator[k];
+  for (int k = 0; k < m->nq; k++) s->qpos[(size_t)i * m->nq + k] = (real)d->qpos[k];
+  for (int k = 0; k < m->nv; k++) s->qvel[(size_t)i * m->nv + k] = (real)d->qvel[k];
+  for (int k = 0; k < m->nv; k++) s->qacc_warmstart[(size_t)i * m->nv + k] = (real)d->qacc_warmstart[k];
+  for (int k = 0; k < m->nu; k++) s->act[(size_t)i * m->nu + k] = (real)d->act[k];
+  for (int k = 0; k < 3 * m->nbody; k++) s->xpos[(size_t)i * 3 * m->nbody + k] = (real)d->xpos[k];
+  for (int k = 0; k < 9; k++) s->xmat1[(size_t)i * 9 + k] = (real)d->xmat[9 + k];
+  for (int k = 0; k < 3; k++) s->com1[(size_t)i * 3 + k] = (real)d->subtree_com[3 + k];
+  for (int k = 0; k < m->nv; k++) s->qfrc_actuator[(size_t)i * m->nv + k] = (real)d->qfrc_actuator[k];
 }
 
 static int obs_size(const orc_model *m, const orc_envspec *e) { return m->nq + 2 * m->nv + 3 * e->nee; }
@@ -1148,7 +1150,7 @@ static int traj_size(const orc_envspec *e) { return e->ref_len * (3 * e->napp + 
 
 /* rodent.py:119-176 reset: explicit start_frame and (already scaled) noise replace the JAX PRNG */
 int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const int32_t *start_frame,
-                  const float *noise, orc_state *s) {
+                  const real *noise, orc_state *s) {
   int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e);
   real *obs = ralloc(no), *traj = ralloc(nt);
   orc_data *d = orc_data_create(m);
@@ -1167,12 +1169,12 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
     store_state(m, d, s, i);
     env_traj(m, e, c, d, start_frame[i], traj);
     env_obs(m, e, d, obs);
-    for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (float)obs[k];
-    for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (float)traj[k];
+    for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (real)obs[k];
+    for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (real)traj[k];
     s->reward[i] = 0, s->done[i] = 0;
     for (int k = 0; k < 7; k++) s->metrics[(size_t)i * 7 + k] = 0;
     s->cur_frame[i] = start_frame[i], s->sub_clip_frame[i] = 0;
-    s->termination_error[i] = (float)env_termination(m, e, c, d->qpos, d->xpos, start_frame[i]);
+    s->termination_error[i] = (real)env_termination(m, e, c, d->qpos, d->xpos, start_frame[i]);
   }
   orc_data_destroy(d);
   free(obs), free(traj);
@@ -1180,7 +1182,7 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
 }
 
 /* rodent.py:178-239 step */
-int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const float *action,
+int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *action,
                  orc_state *s) {
   int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
 #pragma omp parallel
@@ -1249,14 +1251,14 @@ int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
         if (isnan(obs[k])) obs[k] = 0;
       if (data_has_nan(m, d)) done = 1;
       store_state(m, d, s, i);
-      for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (float)obs[k];
-      for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (float)traj[k];
-      s->reward[i] = (float)total, s->done[i] = (float)done;
-      float *mt = s->metrics + (size_t)i * 7;
-      mt[0] = (float)rcom, mt[1] = (float)rvel, mt[2] = (float)rtrunk, mt[3] = (float)rquat, mt[4] = (float)ract;
-      mt[5] = (float)rapp, mt[6] = (float)rtrunk;
+      for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (real)obs[k];
+      for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (real)traj[k];
+      s->reward[i] = (real)total, s->done[i] = (real)done;
+      real *mt = s->metrics + (size_t)i * 7;
+      mt[0] = (real)rcom, mt[1] = (real)rvel, mt[2] = (real)rtrunk, mt[3] = (real)rquat, mt[4] = (real)ract;
+      mt[5] = (real)rapp, mt[6] = (real)rtrunk;
       s->cur_frame[i] = new_frame, s->sub_clip_frame[i] = new_sub;
-      s->termination_error[i] = (float)rtrunk;
+      s->termination_error[i] = (real)rtrunk;
     }
     orc_data_destroy(d);
     free(obs), free(traj), free(old_qpos), free(old_xpos);

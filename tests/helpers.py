@@ -1,0 +1,98 @@
+"""Shared test scaffolding: fixtures -> model, clip, oracle, and the host simulation
+of the kernels (tests/hostsim) used by the CPU-only tier."""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import os
+import subprocess
+
+import numpy as np
+
+import vnl_brax_imitation_amd  # noqa: F401  (installs the package alias)
+from vnl_brax_imitation_amd import _lib, configs
+from vnl_brax_imitation_amd.envs.rodent import packaged_model_path
+from vnl_brax_imitation_amd.model import blob, mjcf
+from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BODY_IDXS = [1, 8, 9, 10, 11, 13, 14, 15, 54, 55, 56, 57, 58, 60, 61, 62, 63, 65]
+
+
+@functools.lru_cache(maxsize=None)
+def model() -> mjcf.CompiledModel:
+    return mjcf.CompiledModel.load(packaged_model_path())
+
+
+@functools.lru_cache(maxsize=None)
+def golden_clip() -> dict:
+    z = np.load(os.path.join(GOLDEN, "groom_clip.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@functools.lru_cache(maxsize=None)
+def reference_clip() -> pp.ReferenceClip:
+    """66-body features rebuilt from the shipped clip's qpos."""
+    g = golden_clip()
+    q = np.concatenate([g["position"], g["quaternion"], g["joints"]], axis=1)
+    return pp.process_qpos(model(), q)
+
+
+def env_kwargs() -> dict:
+    kw = dict(configs.RODENT_ENV_ARGS)
+    kw["model"] = model()
+    return kw
+
+
+def build_hostsim(real: str = "float") -> str:
+    """g++ build of csrc/vnl_lib.hip against tests/hostsim/stub (kernel launch = serial loop)."""
+    src = os.path.join(ROOT, "vnl-brax-imitation_amd", "csrc")
+    out = os.path.join(ROOT, "tests", "hostsim", "_build", f"libvnl_hostsim_{real}.so")
+    deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".h", ".hip"))]
+    deps += [os.path.join(ROOT, "include", "vnl.h"), os.path.join(ROOT, "tests", "hostsim", "stub", "hip", "hip_runtime.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", f"-DVNL_REAL={real}", "-I" + os.path.join(ROOT, "tests", "hostsim", "stub"),
+                               "-x", "c++", os.path.join(src, "vnl_lib.hip"), "-o", out])
+    return out
+
+
+@functools.lru_cache(maxsize=None)
+def hostsim_library(real: str = "float") -> C.CDLL:
+    return _lib.load_library(build_hostsim(real))
+
+
+def hostsim_env(num_envs: int, real: str = "float", **over):
+    """RodentTracking bound to the host simulation (CPU tensors)."""
+    import torch
+
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+
+    kw = env_kwargs()
+    kw.update(over)
+    clip = kw.pop("reference_clip", None) or reference_clip()
+    return RodentTracking(clip, num_envs=num_envs, device="cpu", _library=hostsim_library(real),
+                          _dtype=torch.float64 if real == "double" else torch.float32, **kw)
+
+
+def make_oracle(env, precision="f64"):
+    """Oracle bound to the same model / clip / effective indices as `env`."""
+    from oracle.oracle import Oracle
+
+    m = env.sys
+    o = Oracle(blob.to_blob(m), precision)
+    o.bind_env(env.env_spec(), env.clip_arrays(0), int(m.scalars["nbody"]), int(m.scalars["nq"]),
+               int(m.scalars["nv"]), int(m.scalars["nu"]))
+    return o
+
+
+def rel_err(a, b, floor=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor)))
+
+
+def scaled_err(a, b):
+    """max |a-b| / max(|b|, tiny): error relative to the array's own scale."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))

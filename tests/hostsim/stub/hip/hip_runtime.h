@@ -1,0 +1,44 @@
+// TEST-ONLY stand-in for <hip/hip_runtime.h>: lets g++ compile the product's
+// csrc/vnl_lib.hip unchanged into a host library in which every "kernel launch"
+// is a serial loop over (block, thread).  It exists so that the kernel LOGIC can be
+// parity-tested against the oracle in the CPU-only container (`-m "not gpu"`),
+// before a GPU is available.  It is never built into, nor reachable from, the
+// product package: the product library is compiled by hipcc against the real HIP
+// runtime and has no CPU path.
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+static thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+#define VNL_WAVE_ANY(x) (x)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
+  do {                                                                         \
+    dim3 g_ = (grid), b_ = (block);                                            \
+    gridDim = g_, blockDim = b_;                                               \
+    for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                  \
+      for (unsigned tx_ = 0; tx_ < b_.x; tx_++) {                              \
+        blockIdx = dim3(bx_), threadIdx = dim3(tx_);                           \
+        kernel(__VA_ARGS__);                                                   \
+      }                                                                        \
+  } while (0)

@@ -1,0 +1,130 @@
+"""ctypes binding of the C-ABI in include/vnl.h (libvnl.so, built by csrc/build.py).
+
+There is no CPU fallback: if the HIP library is missing, `load_library` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libvnl.so")
+
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+
+
+class EnvSpec(C.Structure):
+    _fields_ = [
+        ("clip_frames", C.c_int32),
+        ("num_clips", C.c_int32),
+        ("ref_traj_length", C.c_int32),
+        ("sub_clip_length", C.c_int32),
+        ("n_frames", C.c_int32),
+        ("num_track_bodies", C.c_int32),
+        ("num_end_eff", C.c_int32),
+        ("num_appendages", C.c_int32),
+        ("num_joint_cols", C.c_int32),
+        ("com_ref_col", C.c_int32),
+        ("body_idxs", i32p),
+        ("end_eff_idx", i32p),
+        ("app_body", i32p),
+        ("app_ref_col", i32p),
+        ("joint_cols", i32p),
+        ("healthy_z_lo", C.c_float),
+        ("healthy_z_hi", C.c_float),
+        ("termination_threshold", C.c_float),
+        ("body_error_multiplier", C.c_float),
+        ("position", f32p),
+        ("quaternion", f32p),
+        ("joints", f32p),
+        ("body_positions", f32p),
+        ("velocity", f32p),
+        ("angular_velocity", f32p),
+        ("joints_velocity", f32p),
+    ]
+
+
+STATE_FLOAT_FIELDS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xquat", "subtree_com1", "qfrc_actuator",
+                      "obs", "reward", "done", "metrics", "traj", "termination_error")
+STATE_INT_FIELDS = ("cur_frame", "sub_clip_frame", "clip_id")
+
+
+class StatePtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STATE_FLOAT_FIELDS + STATE_INT_FIELDS]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "nbody", "njnt", "ngeom_collide", "ncon", "nefc",
+                                          "obs_size", "traj_size", "workspace_floats_per_env")]
+
+
+class PolicySpec(C.Structure):
+    _fields_ = [
+        ("traj_size", C.c_int32),
+        ("obs_size", C.c_int32),
+        ("action_size", C.c_int32),
+        ("latent_size", C.c_int32),
+        ("num_encoder_layers", C.c_int32),
+        ("num_decoder_layers", C.c_int32),
+        ("encoder_layers", C.c_int32 * 8),
+        ("decoder_layers", C.c_int32 * 8),
+    ]
+
+
+EXPORTS = (
+    "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
+    "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
+    "vnl_policy_num_params", "vnl_policy_forward",
+)
+
+
+class VnlError(RuntimeError):
+    pass
+
+
+def _declare(lib: C.CDLL) -> C.CDLL:
+    vp = C.c_void_p
+    lib.vnl_last_error.restype = C.c_char_p
+    lib.vnl_version.restype = C.c_int
+    lib.vnl_model_create.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.vnl_model_destroy.argtypes = [vp]
+    lib.vnl_model_destroy.restype = None
+    lib.vnl_env_create.argtypes = [vp, C.POINTER(EnvSpec), C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.vnl_env_destroy.argtypes = [vp]
+    lib.vnl_env_destroy.restype = None
+    lib.vnl_env_dims.argtypes = [vp, C.POINTER(Dims)]
+    lib.vnl_env_reset.argtypes = [vp, vp, vp, C.POINTER(StatePtrs), vp]
+    lib.vnl_env_step.argtypes = [vp, vp, C.POINTER(StatePtrs), vp]
+    lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.vnl_policy_destroy.argtypes = [vp]
+    lib.vnl_policy_destroy.restype = None
+    lib.vnl_policy_num_params.argtypes = [vp]
+    lib.vnl_policy_num_params.restype = C.c_int64
+    lib.vnl_policy_forward.argtypes = [vp] + [vp] * 7 + [C.c_int32, C.c_int32] + [vp] * 6 + [vp]
+    return lib
+
+
+_cache = {}
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libvnl.so.  Raises (loudly) if it has not been built."""
+    path = os.path.abspath(path or os.environ.get("VNL_LIB", DEFAULT_LIB))
+    if path not in _cache:
+        if not os.path.exists(path):
+            raise VnlError(
+                f"HIP extension not found at {path}. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the rollout.")
+        lib = C.CDLL(path)
+        missing = [s for s in EXPORTS if not hasattr(lib, s)]
+        if missing:
+            raise VnlError(f"{path} lacks symbols {missing}")
+        _cache[path] = _declare(lib)
+    return _cache[path]
+
+
+def check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise VnlError(f"vnl error {rc}: {lib.vnl_last_error().decode()}")

@@ -1,0 +1,457 @@
+// C-ABI (include/vnl.h) + kernels of the rodent rollout for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see csrc/build.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vnl.h"
+#include "vnl_body.h"
+#include "vnl_policy.h"
+
+// ----------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) return fail(VNL_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* vnl_last_error(void) { return g_err; }
+extern "C" int vnl_version(void) { return 1; }
+
+// ----------------------------------------------------------------------------- blob
+struct BlobEntry {
+  char name[24];
+  uint32_t dtype, count;
+  uint64_t offset;
+};
+
+struct vnl_model {
+  std::map<std::string, std::vector<double>> f;
+  std::map<std::string, std::vector<int>> i;
+  double scalar(const char* k) const {
+    auto it = f.find(k);
+    return (it == f.end() || it->second.size() != 1) ? NAN : it->second[0];
+  }
+  bool has_f(const char* k, size_t n) const {
+    auto it = f.find(k);
+    return it != f.end() && it->second.size() == n;
+  }
+  bool has_i(const char* k, size_t n) const {
+    auto it = i.find(k);
+    return it != i.end() && it->second.size() == n;
+  }
+};
+
+extern "C" int vnl_model_create(const void* blob, size_t nbytes, vnl_model** out) {
+  if (!blob || !out) return fail(VNL_ERR_ARG, "vnl_model_create: null argument");
+  const uint8_t* b = (const uint8_t*)blob;
+  if (nbytes < 16 || memcmp(b, "VNLMDL01", 8) != 0) return fail(VNL_ERR_BLOB, "bad blob magic");
+  uint32_t ns;
+  memcpy(&ns, b + 8, 4);
+  if (16 + (size_t)ns * sizeof(BlobEntry) > nbytes) return fail(VNL_ERR_BLOB, "truncated blob directory");
+  vnl_model* m = new vnl_model();
+  const BlobEntry* e = (const BlobEntry*)(b + 16);
+  for (uint32_t k = 0; k < ns; k++) {
+    size_t esz = e[k].dtype == 1 ? 8 : 4;
+    if (e[k].offset + esz * e[k].count > nbytes) {
+      delete m;
+      return fail(VNL_ERR_BLOB, "truncated blob section %s", e[k].name);
+    }
+    std::string name(e[k].name, strnlen(e[k].name, 24));
+    if (e[k].dtype == 1) {
+      std::vector<double> v(e[k].count);
+      memcpy(v.data(), b + e[k].offset, 8 * (size_t)e[k].count);
+      m->f[name] = v;
+    } else if (e[k].dtype == 2) {
+      std::vector<int> v(e[k].count);
+      memcpy(v.data(), b + e[k].offset, 4 * (size_t)e[k].count);
+      m->i[name] = v;
+    } else {
+      delete m;
+      return fail(VNL_ERR_BLOB, "unknown dtype in section %s", e[k].name);
+    }
+  }
+  static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ncg", "ncon", "nlimit", "nefc", "timestep",
+                               "tolerance", "ls_tolerance", "impratio", "meaninertia", "iterations",
+                               "ls_iterations", "eulerdamp", "solver_newton"};
+  for (const char* k : need)
+    if (m->scalar(k) != m->scalar(k)) {
+      delete m;
+      return fail(VNL_ERR_BLOB, "blob lacks scalar %s", k);
+    }
+  if (m->scalar("solver_newton") != 0) {
+    delete m;
+    return fail(VNL_ERR_UNSUPPORTED, "only the CG solver is implemented (reference envs/rodent.py:57-60 selects cg)");
+  }
+  *out = m;
+  return VNL_OK;
+}
+extern "C" void vnl_model_destroy(vnl_model* m) { delete m; }
+
+// ----------------------------------------------------------------------------- env
+struct vnl_env {
+  int device = 0, B = 0;
+  DevModel dm{};
+  DevEnv de{};
+  WsLayout L{};
+  vreal* ws = nullptr;
+  std::vector<void*> allocs;
+  std::map<std::string, std::pair<int, int>> sections;  // name -> (offset, count)
+  int block = 64;
+};
+
+template <class T, class S>
+static int upload(vnl_env* env, const std::vector<S>& src, const T** dst) {
+  std::vector<T> tmp(src.begin(), src.end());
+  if (tmp.empty()) tmp.push_back(T(0));
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, tmp.size() * sizeof(T)));
+  env->allocs.push_back(p);
+  HIPCHK(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (const T*)p;
+  return VNL_OK;
+}
+template <class T>
+static int upload_raw(vnl_env* env, const T* src, size_t n, const T** dst) {
+  std::vector<T> tmp(src, src + n);
+  return upload<T, T>(env, tmp, dst);
+}
+
+static int build_dev_model(vnl_env* env, const vnl_model* hm) {
+  DevModel& d = env->dm;
+  auto S = [&](const char* k) { return hm->scalar(k); };
+  d.nq = (int)S("nq"), d.nv = (int)S("nv"), d.nu = (int)S("nu"), d.nbody = (int)S("nbody"), d.njnt = (int)S("njnt");
+  d.ncg = (int)S("ncg"), d.ncon = (int)S("ncon"), d.nlimit = (int)S("nlimit"), d.nefc = (int)S("nefc");
+  d.iterations = (int)S("iterations"), d.ls_iterations = (int)S("ls_iterations"), d.eulerdamp = (int)S("eulerdamp");
+  d.dt = (vreal)S("timestep"), d.tolerance = (vreal)S("tolerance"), d.ls_tolerance = (vreal)S("ls_tolerance");
+  d.scale = (vreal)(S("meaninertia") * (d.nv > 1 ? d.nv : 1));
+  const int nb = d.nbody, nj = d.njnt, nv = d.nv, nu = d.nu, ng = d.ncg;
+  struct Need {
+    const char* k;
+    size_t n;
+    bool isint;
+  } needs[] = {{"body_parentid", (size_t)nb, true}, {"body_jntadr", (size_t)nb, true}, {"body_jntnum", (size_t)nb, true},
+               {"body_rootid", (size_t)nb, true}, {"body_pos", 3u * nb, false}, {"body_quat", 4u * nb, false},
+               {"body_ipos", 3u * nb, false}, {"body_inertia_full", 9u * nb, false}, {"body_mass", (size_t)nb, false},
+               {"body_invweight0", 2u * nb, false}, {"jnt_type", (size_t)nj, true}, {"jnt_qposadr", (size_t)nj, true},
+               {"jnt_dofadr", (size_t)nj, true}, {"jnt_limited", (size_t)nj, true}, {"jnt_pos", 3u * nj, false},
+               {"jnt_axis", 3u * nj, false}, {"jnt_range", 2u * nj, false}, {"jnt_stiffness", (size_t)nj, false},
+               {"jnt_margin", (size_t)nj, false}, {"jnt_solref", 2u * nj, false}, {"jnt_solimp", 5u * nj, false},
+               {"qpos0", (size_t)d.nq, false}, {"qpos_spring", (size_t)d.nq, false}, {"dof_bodyid", (size_t)nv, true},
+               {"dof_parentid", (size_t)nv, true}, {"dof_armature", (size_t)nv, false},
+               {"dof_damping", (size_t)nv, false}, {"dof_invweight0", (size_t)nv, false}, {"act_dof", (size_t)nu, true},
+               {"act_ctrllimited", (size_t)nu, true}, {"act_gain", (size_t)nu, false}, {"act_gear", (size_t)nu, false},
+               {"act_tau", (size_t)nu, false}, {"act_ctrlrange", 2u * nu, false}, {"cg_type", (size_t)ng, true},
+               {"cg_bodyid", (size_t)ng, true}, {"cg_ncon", (size_t)ng, true}, {"cg_conadr", (size_t)ng, true},
+               {"cg_pos", 3u * ng, false}, {"cg_quat", 4u * ng, false}, {"cg_size", 3u * ng, false},
+               {"cg_friction", 3u * ng, false}, {"cg_solref", 2u * ng, false}, {"cg_solimp", 5u * ng, false},
+               {"cg_margin", (size_t)ng, false}, {"gravity", 3, false}, {"plane_pos", 3, false},
+               {"plane_normal", 3, false}};
+  for (auto& n : needs)
+    if (!(n.isint ? hm->has_i(n.k, n.n) : hm->has_f(n.k, n.n)))
+      return fail(VNL_ERR_BLOB, "blob section %s missing or of unexpected size", n.k);
+  auto F = [&](const char* k) -> const std::vector<double>& { return hm->f.at(k); };
+  auto I = [&](const char* k) -> const std::vector<int>& { return hm->i.at(k); };
+
+  // single kinematic tree rooted at body 1 (the spatial reference point is its origin)
+  for (int b = 1; b < nb; b++)
+    if (I("body_rootid")[b] != 1) return fail(VNL_ERR_UNSUPPORTED, "model must be a single tree rooted at body 1");
+  const auto& jt = I("jnt_type");
+  for (int j = 0; j < nj; j++)
+    if (jt[j] != VNL_JNT_FREE && jt[j] != VNL_JNT_HINGE)
+      return fail(VNL_ERR_UNSUPPORTED, "only free and hinge joints are implemented");
+  d.root_free = (I("body_jntnum")[1] > 0 && jt[I("body_jntadr")[1]] == VNL_JNT_FREE) ? 1 : 0;
+  d.root_px = (vreal)F("body_pos")[3], d.root_py = (vreal)F("body_pos")[4], d.root_pz = (vreal)F("body_pos")[5];
+  d.gx = (vreal)F("gravity")[0], d.gy = (vreal)F("gravity")[1], d.gz = (vreal)F("gravity")[2];
+  const auto& pn = F("plane_normal");
+  const auto& pp = F("plane_pos");
+  d.pnx = (vreal)pn[0], d.pny = (vreal)pn[1], d.pnz = (vreal)pn[2];
+  d.ppx = (vreal)pp[0], d.ppy = (vreal)pp[1], d.ppz = (vreal)pp[2];
+  {  // math.make_frame(n)[1]
+    double a[3] = {pn[0], pn[1], pn[2]}, bb[3] = {0, 0, 0};
+    if (-0.5 < a[1] && a[1] < 0.5) bb[1] = 1; else bb[2] = 1;
+    double ab = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2];
+    for (int k = 0; k < 3; k++) bb[k] -= a[k] * ab;
+    double nn = sqrt(bb[0] * bb[0] + bb[1] * bb[1] + bb[2] * bb[2]);
+    d.t1x = (vreal)(bb[0] / nn), d.t1y = (vreal)(bb[1] / nn), d.t1z = (vreal)(bb[2] / nn);
+  }
+  double tm = 0;
+  for (double x : F("body_mass")) tm += x;
+  d.total_mass_inv = (vreal)(1.0 / tm);
+
+  int rc;
+#define UPF(name, vec) if ((rc = upload<vreal, double>(env, vec, &d.name)) != VNL_OK) return rc;
+#define UPI(name, vec) if ((rc = upload<int, int>(env, vec, &d.name)) != VNL_OK) return rc;
+  UPI(body_parent, I("body_parentid")) UPI(body_jntadr, I("body_jntadr")) UPI(body_jntnum, I("body_jntnum"))
+  UPF(body_pos, F("body_pos")) UPF(body_quat, F("body_quat")) UPF(body_ipos, F("body_ipos")) UPF(body_mass, F("body_mass"))
+  {
+    std::vector<double> i6(6 * (size_t)nb);
+    const auto& f9 = F("body_inertia_full");
+    for (int b = 0; b < nb; b++) {
+      const double* s = &f9[9 * (size_t)b];
+      double* o = &i6[6 * (size_t)b];
+      o[0] = s[0], o[1] = s[4], o[2] = s[8], o[3] = s[1], o[4] = s[2], o[5] = s[5];
+    }
+    UPF(body_inertia6, i6)
+  }
+  UPI(jnt_type, jt) UPI(jnt_qposadr, I("jnt_qposadr")) UPI(jnt_dofadr, I("jnt_dofadr"))
+  UPF(jnt_pos, F("jnt_pos")) UPF(jnt_axis, F("jnt_axis")) UPF(jnt_stiffness, F("jnt_stiffness"))
+  {
+    std::vector<double> q0(nj), qs(nj);
+    for (int j = 0; j < nj; j++) q0[j] = F("qpos0")[I("jnt_qposadr")[j]], qs[j] = F("qpos_spring")[I("jnt_qposadr")[j]];
+    UPF(jnt_qpos0, q0) UPF(jnt_springref, qs)
+  }
+  {  // limit rows
+    std::vector<int> qa, dof;
+    std::vector<double> lo, hi, mg, iw, sr, si;
+    for (int j = 0; j < nj; j++) {
+      if (!I("jnt_limited")[j] || jt[j] != VNL_JNT_HINGE) continue;
+      qa.push_back(I("jnt_qposadr")[j]), dof.push_back(I("jnt_dofadr")[j]);
+      lo.push_back(F("jnt_range")[2 * j]), hi.push_back(F("jnt_range")[2 * j + 1]), mg.push_back(F("jnt_margin")[j]);
+      iw.push_back(F("dof_invweight0")[I("jnt_dofadr")[j]]);
+      for (int k = 0; k < 2; k++) sr.push_back(F("jnt_solref")[2 * j + k]);
+      for (int k = 0; k < 5; k++) si.push_back(F("jnt_solimp")[5 * j + k]);
+    }
+    if ((int)qa.size() != d.nlimit) return fail(VNL_ERR_BLOB, "nlimit does not match jnt_limited");
+    UPI(lim_qadr, qa) UPI(lim_dof, dof) UPF(lim_lo, lo) UPF(lim_hi, hi) UPF(lim_margin, mg) UPF(lim_invweight, iw)
+    UPF(lim_solref, sr) UPF(lim_solimp, si)
+  }
+  {  // tree-sparse layout of qM (MuJoCo dof_Madr order: self, parent, grandparent, ...)
+    const auto& par = I("dof_parentid");
+    std::vector<int> madr(nv), depth(nv), anc;
+    for (int i = 0; i < nv; i++) {
+      madr[i] = (int)anc.size();
+      int dep = 0;
+      for (int j = i; j >= 0; j = par[j]) anc.push_back(j), dep++;
+      depth[i] = dep - 1;
+    }
+    d.nM = (int)anc.size();
+    UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc)
+  }
+  UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
+  UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
+  UPF(act_tau, F("act_tau")) UPF(act_gear, F("act_gear"))
+  {
+    std::vector<double> lo(nu), hi(nu);
+    for (int k = 0; k < nu; k++) lo[k] = F("act_ctrlrange")[2 * k], hi[k] = F("act_ctrlrange")[2 * k + 1];
+    UPF(act_lo, lo) UPF(act_hi, hi)
+  }
+  UPI(cg_type, I("cg_type")) UPI(cg_body, I("cg_bodyid")) UPI(cg_conadr, I("cg_conadr")) UPI(cg_ncon, I("cg_ncon"))
+  UPF(cg_pos, F("cg_pos")) UPF(cg_quat, F("cg_quat")) UPF(cg_size, F("cg_size")) UPF(cg_solref, F("cg_solref"))
+  UPF(cg_solimp, F("cg_solimp")) UPF(cg_margin, F("cg_margin"))
+  {
+    std::vector<double> mu(ng), iw(ng);
+    double impratio = S("impratio");
+    for (int g = 0; g < ng; g++) {
+      mu[g] = F("cg_friction")[3 * g];
+      double t = F("body_invweight0")[0] + F("body_invweight0")[2 * (size_t)I("cg_bodyid")[g]];
+      iw[g] = (t + mu[g] * mu[g] * t) * 2 * mu[g] * mu[g] / impratio;  // constraint._instantiate_contact
+    }
+    UPF(cg_mu, mu) UPF(cg_invweight, iw)
+  }
+#undef UPF
+#undef UPI
+  return VNL_OK;
+}
+
+static void layout(vnl_env* env) {
+  const DevModel& d = env->dm;
+  WsLayout& L = env->L;
+  int o = 0;
+  auto sec = [&](const char* name, int n) {
+    int at = o;
+    env->sections[name] = {at, n};
+    o += n;
+    return at;
+  };
+  L.ctrl = sec("ctrl", d.nu), L.actdot = sec("act_dot", d.nu);
+  L.cdof = sec("cdof", 6 * d.nv), L.cinert = sec("cinert", 10 * d.nbody);
+  L.M = sec("qM", d.nM), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
+  L.bodyA = sec("bodyA", 10 * d.nbody), L.bodyB = sec("bodyB", 12 * d.nbody), L.bodyC = sec("bodyC", 12 * d.nbody);
+  L.bias = sec("qfrc_bias", d.nv), L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv);
+  L.qacc = sec("qacc", d.nv), L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv);
+  L.search = sec("search", d.nv), L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv);
+  L.tmp = sec("tmp", d.nv);
+  L.con_dist = sec("con_dist", d.ncon), L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncon);
+  L.lim_sign = sec("lim_sign", d.nlimit);
+  L.efc_D = sec("efc_D", d.nefc), L.efc_aref = sec("efc_aref", d.nefc), L.Jaref = sec("Jaref", d.nefc);
+  L.jv = sec("jv", d.nefc);
+  L.total = o;
+}
+
+extern "C" void vnl_env_destroy(vnl_env* env) {
+  if (!env) return;
+  for (void* p : env->allocs) (void)hipFree(p);
+  delete env;
+}
+
+extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_t num_envs, int32_t device,
+                              vnl_env** out) {
+  if (!hm || !es || !out || num_envs <= 0) return fail(VNL_ERR_ARG, "vnl_env_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(VNL_ERR_NO_DEVICE, "no HIP device: the rollout has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(VNL_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  vnl_env* env = new vnl_env();
+  env->device = device, env->B = num_envs;
+  int rc = build_dev_model(env, hm);
+  if (rc != VNL_OK) {
+    vnl_env_destroy(env);
+    return rc;
+  }
+  const DevModel& d = env->dm;
+  DevEnv& e = env->de;
+  e.T = es->clip_frames, e.C = es->num_clips, e.ref_len = es->ref_traj_length, e.sub_clip_length = es->sub_clip_length;
+  e.n_frames = es->n_frames, e.nb = es->num_track_bodies, e.nee = es->num_end_eff, e.napp = es->num_appendages;
+  e.njc = es->num_joint_cols, e.com_ref_col = es->com_ref_col;
+  e.healthy_lo = es->healthy_z_lo, e.healthy_hi = es->healthy_z_hi;
+  e.inv_term_threshold = vreal(1) / es->termination_threshold, e.body_err_mult = es->body_error_multiplier;
+  e.obs_size = d.nq + 2 * d.nv + 3 * e.nee;
+  e.traj_size = e.ref_len * (3 * e.napp + 6 * e.nb + 3 + e.njc);
+  bool ok = e.T >= e.ref_len && e.C >= 1 && e.nb >= 1 && e.com_ref_col >= 0 && e.com_ref_col < e.nb && d.nq >= 7 &&
+            d.root_free;
+  for (int k = 0; ok && k < e.nb; k++) ok = es->body_idxs[k] >= 0 && es->body_idxs[k] < d.nbody;
+  for (int k = 0; ok && k < e.nee; k++) ok = es->end_eff_idx[k] >= 0 && es->end_eff_idx[k] < d.nbody;
+  for (int k = 0; ok && k < e.napp; k++)
+    ok = es->app_body[k] >= 0 && es->app_body[k] < d.nbody && es->app_ref_col[k] >= 0 && es->app_ref_col[k] < e.nb;
+  for (int k = 0; ok && k < e.njc; k++) ok = es->joint_cols[k] >= 0 && es->joint_cols[k] < d.nq - 7;
+  if (!ok) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_ARG, "vnl_envspec: index out of range or unsupported shape");
+  }
+  size_t CT = (size_t)e.C * e.T, nj = d.nq - 7;
+#define UP(call)              \
+  if ((rc = (call)) != VNL_OK) { \
+    vnl_env_destroy(env);     \
+    return rc;                \
+  }
+  UP(upload_raw<int>(env, es->body_idxs, e.nb, &e.body_idxs))
+  UP(upload_raw<int>(env, es->end_eff_idx, e.nee, &e.end_eff_idx))
+  UP(upload_raw<int>(env, es->app_body, e.napp, &e.app_body))
+  UP(upload_raw<int>(env, es->app_ref_col, e.napp, &e.app_ref_col))
+  UP(upload_raw<int>(env, es->joint_cols, e.njc, &e.joint_cols))
+  UP(upload_raw<float>(env, es->position, CT * 3, &e.position))
+  UP(upload_raw<float>(env, es->quaternion, CT * 4, &e.quaternion))
+  UP(upload_raw<float>(env, es->joints, CT * nj, &e.joints))
+  UP(upload_raw<float>(env, es->body_positions, CT * e.nb * 3, &e.body_positions))
+  UP(upload_raw<float>(env, es->velocity, CT * 3, &e.velocity))
+  UP(upload_raw<float>(env, es->angular_velocity, CT * 3, &e.angular_velocity))
+  UP(upload_raw<float>(env, es->joints_velocity, CT * nj, &e.joints_velocity))
+#undef UP
+  layout(env);
+  size_t wsbytes = (size_t)env->L.total * num_envs * sizeof(vreal);
+  if ((size_t)env->L.total * num_envs >= (1ull << 31)) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_ARG, "num_envs too large for 32-bit scratch indexing");
+  }
+  void* p = nullptr;
+  hipError_t he = hipMalloc(&p, wsbytes);
+  if (he != hipSuccess) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_HIP, "hipMalloc(scratch): %s", hipGetErrorString(he));
+  }
+  env->allocs.push_back(p);
+  env->ws = (vreal*)p;
+  he = hipMemset(p, 0, wsbytes);
+  if (he != hipSuccess) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_HIP, "hipMemset(scratch): %s", hipGetErrorString(he));
+  }
+  const char* bs = getenv("VNL_BLOCK");
+  if (bs && atoi(bs) > 0 && atoi(bs) % 64 == 0 && atoi(bs) <= 256) env->block = atoi(bs);
+  *out = env;
+  return VNL_OK;
+}
+
+extern "C" int vnl_env_dims(const vnl_env* env, vnl_dims* o) {
+  if (!env || !o) return fail(VNL_ERR_ARG, "vnl_env_dims: null argument");
+  const DevModel& d = env->dm;
+  o->nq = d.nq, o->nv = d.nv, o->nu = d.nu, o->nbody = d.nbody, o->njnt = d.njnt, o->ngeom_collide = d.ncg;
+  o->ncon = d.ncon, o->nefc = d.nefc, o->obs_size = env->de.obs_size, o->traj_size = env->de.traj_size;
+  o->workspace_floats_per_env = env->L.total;
+  return VNL_OK;
+}
+
+extern "C" int vnl_env_scratch(const vnl_env* env, const char* name, float** dev_ptr, int32_t* count) {
+  if (!env || !name || !dev_ptr || !count) return fail(VNL_ERR_ARG, "vnl_env_scratch: null argument");
+  auto it = env->sections.find(name);
+  if (it == env->sections.end()) return fail(VNL_ERR_ARG, "unknown scratch section %s", name);
+  *dev_ptr = (float*)(env->ws + (size_t)it->second.first * env->B);
+  *count = it->second.second;
+  return VNL_OK;
+}
+
+// ----------------------------------------------------------------------------- kernels
+// One env per lane.  64-thread workgroups: at 4096 envs the grid is 64 waves, one per CU,
+// so each wave owns a CU's scheduler, L1 and scalar cache (occupancy note).
+__global__ void __launch_bounds__(256) vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, vreal* ws,
+                                                        const vreal* action, unsigned B) {
+  unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  EnvLane lane{m, ev, st, L, ws, B, e};
+  lane.step(action);
+}
+
+__global__ void __launch_bounds__(256) vnl_reset_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, vreal* ws,
+                                                         const int* start_frame, const vreal* noise, unsigned B) {
+  unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  EnvLane lane{m, ev, st, L, ws, B, e};
+  lane.reset(start_frame, noise);
+}
+
+static int to_dev_state(const vnl_state* s, DevState* d) {
+  const void* ptrs[] = {s->qpos, s->qvel, s->act, s->qacc_warmstart, s->xpos, s->xquat, s->subtree_com1,
+                        s->qfrc_actuator, s->obs, s->reward, s->done, s->metrics, s->traj, s->termination_error,
+                        s->cur_frame, s->sub_clip_frame, s->clip_id};
+  for (const void* p : ptrs)
+    if (!p) return fail(VNL_ERR_ARG, "vnl_state: null buffer");
+  // (vreal is float in the product; the casts only matter for the float64 test build)
+  d->qpos = (vreal*)s->qpos, d->qvel = (vreal*)s->qvel, d->act = (vreal*)s->act, d->warm = (vreal*)s->qacc_warmstart;
+  d->xpos = (vreal*)s->xpos, d->xquat = (vreal*)s->xquat, d->com1 = (vreal*)s->subtree_com1;
+  d->qfrc_actuator = (vreal*)s->qfrc_actuator, d->obs = (vreal*)s->obs, d->reward = (vreal*)s->reward;
+  d->done = (vreal*)s->done, d->metrics = (vreal*)s->metrics, d->traj = (vreal*)s->traj;
+  d->term_err = (vreal*)s->termination_error, d->cur_frame = s->cur_frame, d->sub_clip_frame = s->sub_clip_frame;
+  d->clip_id = s->clip_id;
+  return VNL_OK;
+}
+
+extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const float* noise, const vnl_state* state,
+                             void* stream) {
+  if (!env || !start_frame || !noise || !state) return fail(VNL_ERR_ARG, "vnl_env_reset: null argument");
+  DevState ds;
+  int rc = to_dev_state(state, &ds);
+  if (rc != VNL_OK) return rc;
+  unsigned B = env->B, grid = (B + env->block - 1) / env->block;
+  hipLaunchKernelGGL(vnl_reset_kernel, dim3(grid), dim3(env->block), 0, (hipStream_t)stream, env->dm, env->de, ds,
+                     env->L, env->ws, (const int*)start_frame, (const vreal*)noise, B);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
+extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* state, void* stream) {
+  if (!env || !action || !state) return fail(VNL_ERR_ARG, "vnl_env_step: null argument");
+  DevState ds;
+  int rc = to_dev_state(state, &ds);
+  if (rc != VNL_OK) return rc;
+  unsigned B = env->B, grid = (B + env->block - 1) / env->block;
+  hipLaunchKernelGGL(vnl_step_kernel, dim3(grid), dim3(env->block), 0, (hipStream_t)stream, env->dm, env->de, ds,
+                     env->L, env->ws, (const vreal*)action, B);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
+// ----------------------------------------------------------------------------- policy
+#include "vnl_policy_impl.h"

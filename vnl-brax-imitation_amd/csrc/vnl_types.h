@@ -1,0 +1,76 @@
+// Device-side tables passed to the kernels BY VALUE (kernarg segment -> SGPRs).
+// Every table pointer is read with wave-uniform indices, so hipcc emits scalar
+// loads (s_load_*) through the constant cache; no LDS staging is needed for them.
+#pragma once
+#include <stdint.h>
+
+// Arithmetic type of the kernels.  The product is float32 (JAX default in the
+// reference).  Tests build a float64 host simulation (-DVNL_REAL=double) to show the
+// algorithms agree with the dense oracle far below float32 rounding.
+#ifndef VNL_REAL
+#define VNL_REAL float
+#endif
+typedef VNL_REAL vreal;
+
+#define VNL_JNT_FREE 0
+#define VNL_JNT_HINGE 3
+#define VNL_GEOM_SPHERE 2
+#define VNL_GEOM_CAPSULE 3
+#define VNL_GEOM_ELLIPSOID 4
+
+struct DevModel {
+  int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
+  int iterations, ls_iterations, eulerdamp, root_free;
+  vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
+  vreal gx, gy, gz;
+  vreal pnx, pny, pnz, ppx, ppy, ppz; /* plane normal / point */
+  vreal t1x, t1y, t1z;                /* make_frame(n)[1] (frame[2] = n x t1) */
+  vreal total_mass_inv;
+  vreal root_px, root_py, root_pz; /* reference point when the root is not a free joint */
+  // bodies
+  const int *body_parent, *body_jntadr, *body_jntnum;
+  const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
+  // joints
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr;
+  const vreal *jnt_pos, *jnt_axis, *jnt_qpos0, *jnt_stiffness, *jnt_springref;
+  // limit rows (one per limited hinge)
+  const int *lim_qadr, *lim_dof;
+  const vreal *lim_lo, *lim_hi, *lim_margin, *lim_invweight, *lim_solref, *lim_solimp;
+  // dofs
+  const int *dof_body, *dof_Madr, *dof_depth, *M_anc;
+  const vreal *dof_armature, *dof_damping;
+  // actuators
+  const int *act_dof, *act_limited;
+  const vreal *act_gain, *act_tau, *act_lo, *act_hi, *act_gear;
+  // collidable geoms (all against the one plane)
+  const int *cg_type, *cg_body, *cg_conadr, *cg_ncon;
+  const vreal *cg_pos, *cg_quat, *cg_size, *cg_mu, *cg_solref, *cg_solimp, *cg_margin, *cg_invweight;
+};
+
+struct DevEnv {
+  int T, C, ref_len, sub_clip_length, n_frames, nb, nee, napp, njc, com_ref_col;
+  int obs_size, traj_size;
+  vreal healthy_lo, healthy_hi, inv_term_threshold, body_err_mult;
+  const int *body_idxs, *end_eff_idx, *app_body, *app_ref_col, *joint_cols;
+  const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
+};
+
+// caller-owned SoA buffers (see include/vnl.h vnl_state)
+struct DevState {
+  vreal *qpos, *qvel, *act, *warm, *xpos, *xquat, *com1, *qfrc_actuator;
+  vreal *obs, *reward, *done, *metrics, *traj, *term_err;
+  int *cur_frame, *sub_clip_frame, *clip_id;
+};
+
+// per-env scratch sections (offsets in floats; element k of section s for env e
+// lives at ws[(s + k) * B + e])
+struct WsLayout {
+  int ctrl, actdot;
+  int cdof, cinert, M, LD, dinv;
+  int bodyA, bodyB, bodyC; /* 3 x (10*nbody): crb | cvel,cacc,cfrc | V, F/W */
+  int bias, smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp;
+  int con_dist, con_r, con_t1;
+  int lim_sign;
+  int efc_D, efc_aref, Jaref, jv;
+  int total;
+};
