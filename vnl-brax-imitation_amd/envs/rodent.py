@@ -268,7 +268,12 @@ class RodentTracking(Env):
             raise ValueError(f"action must be ({B},{nu}), got {tuple(action.shape)}")
         a = a.to(device=self.device, dtype=self._dtype).contiguous()
         p = self._ptrs(state)
+        ev = getattr(self, "kernel_events", None)  # (start, end) torch.cuda.Event pair, used by bench.py
+        if ev is not None:
+            ev[0].record()
         _lib.check(self._L, self._L.vnl_env_step(self._env_h, a.data_ptr(), C.byref(p), self._stream()))
+        if ev is not None:
+            ev[1].record()
         self._hold = (a,)
         return state
 
