@@ -29,6 +29,14 @@ class Wrapper(Env):
     def unwrapped(self) -> Env:
         return self.env.unwrapped
 
+    @property
+    def observation_size(self) -> int:
+        return self.env.observation_size
+
+    @property
+    def action_size(self) -> int:
+        return self.env.action_size
+
     def reset(self, rng=None, **kw) -> State:
         return self.env.reset(rng, **kw)
 

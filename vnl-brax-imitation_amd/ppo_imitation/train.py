@@ -1,0 +1,293 @@
+"""PPO training with the intention policy: counterpart of reference ppo_imitation/train.py:62-491.
+
+Same keyword signature and return triple `(make_policy, params, metrics)`; same loop structure
+(unroll -> normaliser update -> num_updates_per_batch x num_minibatches SGD steps).
+
+MI355X mapping of the reference's jax.pmap data parallelism (train.py:363):
+  * one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI); `environment`
+    is this rank's shard of the envs (its `num_envs` = per-rank envs);
+  * C1: gradients live in ONE flat float32 buffer (policy | value) -> one RCCL all-reduce per
+    minibatch step, averaged (brax gradient_update_fn pmean, train.py:251-253,264-266);
+  * C2: normaliser statistics all-reduced once per training step (train.py:330-334);
+  * C3: parameters broadcast from rank 0 at init (train.py:410-412);
+  * C4: replicas are checked bit-identical at the end (train.py:485-487).
+Nothing else crosses the links; rollout, GAE, advantage normalisation and shuffling are local.
+"""
+from __future__ import annotations
+
+import dataclasses
+import functools
+import logging
+import time
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..envs import wrappers as env_wrappers
+from . import acting, ppo_networks, running_statistics
+from . import intention_losses as ppo_losses
+
+Metrics = Dict[str, Any]
+
+
+@dataclasses.dataclass
+class TrainingState:
+    """train.py:38-45."""
+
+    optimizer_state: Dict[str, torch.Tensor]
+    params: torch.Tensor  # flat [policy | value]
+    normalizer_params: running_statistics.RunningStatisticsState
+    env_steps: int
+
+
+class FlatAdam:
+    """optax.adam(lr) [UPSTREAM] on one flat buffer: b1=0.9, b2=0.999, eps=1e-8, no weight decay."""
+
+    def __init__(self, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+
+    def init(self, params: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {"mu": torch.zeros_like(params), "nu": torch.zeros_like(params),
+                "count": torch.zeros((), dtype=torch.int64)}
+
+    @torch.no_grad()
+    def update(self, grads: torch.Tensor, state: Dict[str, torch.Tensor], params: torch.Tensor) -> None:
+        state["count"] += 1
+        t = int(state["count"])
+        state["mu"].mul_(self.b1).add_(grads, alpha=1 - self.b1)
+        state["nu"].mul_(self.b2).addcmul_(grads, grads, value=1 - self.b2)
+        bc1, bc2 = 1 - self.b1 ** t, 1 - self.b2 ** t
+        denom = (state["nu"] / bc2).sqrt_().add_(self.eps)
+        params.addcdiv_(state["mu"], denom, value=-self.lr / bc1)
+
+
+def _dist_info():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def train(
+    environment,
+    num_timesteps: int,
+    episode_length: int,
+    action_repeat: int = 1,
+    num_envs: int = 1,
+    max_devices_per_host: Optional[int] = None,
+    num_eval_envs: int = 128,
+    learning_rate: float = 1e-4,
+    entropy_cost: float = 1e-4,
+    discounting: float = 0.9,
+    seed: int = 0,
+    unroll_length: int = 10,
+    batch_size: int = 32,
+    num_minibatches: int = 16,
+    num_updates_per_batch: int = 2,
+    num_evals: int = 1,
+    num_resets_per_eval: int = 0,
+    normalize_observations: bool = False,
+    reward_scaling: float = 1.0,
+    clipping_epsilon: float = 0.3,
+    gae_lambda: float = 0.95,
+    deterministic_eval: bool = False,
+    network_factory=ppo_networks.make_intention_ppo_networks,
+    progress_fn: Callable[[int, Metrics], None] = lambda *args: None,
+    normalize_advantage: bool = True,
+    eval_env=None,
+    policy_params_fn: Callable[..., None] = lambda *args: None,
+    randomization_fn=None,
+    kl_weight: float = 1e-4,
+    reset_info_on_autoreset: bool = False,
+):
+    """PPO training (train.py:62-491).
+
+    `num_envs`, `batch_size` are GLOBAL counts as in the reference (train.py:128-129 scales them by
+    the device count); each rank owns `num_envs // world` envs -- `environment.num_envs` must equal
+    that -- and `batch_size // world` trajectories per minibatch.
+    """
+    dist, rank, world = _dist_info()
+    assert batch_size * num_minibatches % num_envs == 0
+    assert num_envs % world == 0 and batch_size % world == 0
+    local_envs, local_batch = num_envs // world, batch_size // world
+    base = environment.unwrapped
+    assert base.num_envs == local_envs, f"environment.num_envs={base.num_envs}, expected {local_envs} per rank"
+    device = base.device
+    xt = time.time()
+
+    env_step_per_training_step = batch_size * unroll_length * num_minibatches * action_repeat
+    num_evals_after_init = max(num_evals - 1, 1)
+    num_training_steps_per_epoch = int(np.ceil(
+        num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
+
+    # keys: networks global (identical on all ranks), env / sgd streams per rank (train.py:178-187)
+    g_net = torch.Generator(device="cpu").manual_seed(seed)
+    g_env = torch.Generator(device="cpu").manual_seed(seed * 1000003 + 17 + rank)
+    g_dev = torch.Generator(device=device).manual_seed(seed * 7919 + 101 + rank) if device.type == "cuda" else g_env
+    g_eval = torch.Generator(device="cpu").manual_seed(seed * 31 + 7)
+
+    env = env_wrappers.wrap(environment, episode_length=episode_length, action_repeat=action_repeat,
+                            randomization_fn=randomization_fn, reset_info_on_autoreset=reset_info_on_autoreset)
+    env_state = env.reset(g_env)
+
+    normalize = (lambda x, y: x)
+    if normalize_observations:
+        normalize = running_statistics.normalize
+    ppo_network = network_factory(env_state.info["traj"].shape[-1], env_state.obs.shape[-1], env.action_size,
+                                  preprocess_observations_fn=normalize)
+    make_policy = ppo_networks.make_inference_fn(ppo_network)
+
+    n_pol, n_val = ppo_network.policy_network.layout.size, ppo_network.value_network.layout.size
+    flat = torch.cat([ppo_network.policy_network.init(g_net), ppo_network.value_network.init(g_net)]).to(device)
+    if dist is not None:
+        dist.broadcast(flat, src=0)  # C3
+    flat.requires_grad_(True)
+    optimizer = FlatAdam(learning_rate)
+    training_state = TrainingState(
+        optimizer_state={k: v.to(device) if v.dim() else v for k, v in optimizer.init(flat.detach()).items()},
+        params=flat,
+        normalizer_params=running_statistics.init_state(env_state.obs.shape[-1], device=device),
+        env_steps=0,
+    )
+
+    def split(p: torch.Tensor) -> ppo_losses.PPONetworkParams:
+        return ppo_losses.PPONetworkParams(policy=p[:n_pol], value=p[n_pol:])
+
+    loss_fn = functools.partial(
+        ppo_losses.compute_ppo_intention_loss, ppo_network=ppo_network, entropy_cost=entropy_cost,
+        discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
+        clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage, kl_weight=kl_weight)
+
+    def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
+        """train.py:255-268 + brax gradient_update_fn: grad, all-reduce(mean), adam."""
+        p = training_state.params
+        p.grad = None
+        loss, metrics = loss_fn(split(p), normalizer_params, data, g_dev)
+        loss.backward()
+        if dist is not None:
+            dist.all_reduce(p.grad)  # C1: one flat buffer
+            p.grad.div_(world)
+        optimizer.update(p.grad, training_state.optimizer_state, p.data)
+        return metrics
+
+    def sgd_step(data: acting.Transition, normalizer_params) -> Metrics:
+        """train.py:270-291: one shared permutation, num_minibatches steps."""
+        n = data.reward.shape[0]
+        perm = torch.randperm(n, generator=g_env).to(device)
+        acc: Dict[str, torch.Tensor] = {}
+        mb = n // num_minibatches
+        for i in range(num_minibatches):
+            idx = perm[i * mb:(i + 1) * mb]
+            m = minibatch_step(data.map(lambda x: x.index_select(0, idx)), normalizer_params)
+            for k, v in m.items():
+                acc[k] = acc.get(k, 0) + v
+        return {k: v / num_minibatches for k, v in acc.items()}
+
+    def training_step() -> Metrics:
+        """train.py:293-349."""
+        nonlocal env_state
+        policy = make_policy((training_state.normalizer_params, training_state.params.detach()[:n_pol]))
+        chunks = []
+        for _ in range(batch_size * num_minibatches // num_envs):
+            env_state, data = acting.generate_unroll(env, env_state, policy, g_dev, unroll_length,
+                                                     extra_fields=("truncation", "traj"))
+            chunks.append(data)
+        # [U, T, B, ...] -> swapaxes(1,2) -> reshape(-1, T, ...)   (train.py:323-327)
+        data = chunks[0].map(lambda x: x) if len(chunks) == 1 else None
+        if data is None:
+            keys = chunks[0]
+            data = acting.Transition(
+                *[torch.stack([getattr(c, f) for c in chunks]) for f in
+                  ("observation", "action", "reward", "discount", "next_observation")],
+                extras={g: {k: torch.stack([c.extras[g][k] for c in chunks]) for k in keys.extras[g]}
+                        for g in keys.extras})
+            data = data.map(lambda x: x.transpose(1, 2).reshape(-1, *x.shape[1:2], *x.shape[3:]))
+        else:
+            data = data.map(lambda x: x.transpose(0, 1))
+        assert data.discount.shape[1:] == (unroll_length,)
+        normalizer_params = running_statistics.update(training_state.normalizer_params, data.observation,
+                                                      distributed=dist is not None)  # C2
+        acc: Dict[str, torch.Tensor] = {}
+        for _ in range(num_updates_per_batch):
+            m = sgd_step(data, normalizer_params)
+            for k, v in m.items():
+                acc[k] = acc.get(k, 0) + v
+        training_state.normalizer_params = normalizer_params
+        training_state.env_steps += env_step_per_training_step
+        return {k: v / num_updates_per_batch for k, v in acc.items()}
+
+    training_walltime = 0.0
+
+    def training_epoch_with_timing() -> Metrics:
+        """train.py:351-394."""
+        nonlocal training_walltime
+        t = time.time()
+        acc: Dict[str, torch.Tensor] = {}
+        for _ in range(num_training_steps_per_epoch):
+            m = training_step()
+            for k, v in m.items():
+                acc[k] = acc.get(k, 0) + v
+        metrics = {k: float(v / num_training_steps_per_epoch) for k, v in acc.items()}  # blocks (like :376)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        epoch_training_time = time.time() - t
+        training_walltime += epoch_training_time
+        sps = (num_training_steps_per_epoch * env_step_per_training_step * max(num_resets_per_eval, 1)) / epoch_training_time
+        return {"training/sps": sps, "training/walltime": training_walltime,
+                **{f"training/{name}": value for name, value in metrics.items()}}
+
+    if not eval_env:
+        eval_env = environment
+    evaluator = None
+    if rank == 0 and eval_env is not None and num_eval_envs > 0:
+        ev_wrapped = env_wrappers.wrap(eval_env, episode_length=episode_length, action_repeat=action_repeat,
+                                       reset_info_on_autoreset=reset_info_on_autoreset)
+        evaluator = acting.Evaluator(ev_wrapped, functools.partial(make_policy, deterministic=deterministic_eval),
+                                     num_eval_envs=eval_env.unwrapped.num_envs, episode_length=episode_length,
+                                     action_repeat=action_repeat, key=g_eval)
+
+    def inference_params():
+        return (training_state.normalizer_params.clone(), training_state.params.detach()[:n_pol].clone())
+
+    metrics: Metrics = {}
+    if rank == 0 and num_evals > 1 and evaluator is not None:
+        metrics = evaluator.run_evaluation(inference_params(), training_metrics={})
+        logging.info(metrics)
+        progress_fn(0, metrics)
+        if eval_env is environment:
+            env_state = env.reset(g_env)
+
+    training_metrics: Metrics = {}
+    current_step = 0
+    for it in range(num_evals_after_init):
+        logging.info("starting iteration %s %s", it, time.time() - xt)
+        for _ in range(max(num_resets_per_eval, 1)):
+            training_metrics = training_epoch_with_timing()
+            current_step = training_state.env_steps
+            if num_resets_per_eval > 0:
+                env_state = env.reset(g_env)
+        if rank == 0:
+            metrics = training_metrics
+            if evaluator is not None:
+                metrics = evaluator.run_evaluation(inference_params(), training_metrics)
+                if eval_env is environment:
+                    env_state = env.reset(g_env)
+            logging.info(metrics)
+            progress_fn(current_step, metrics)
+            policy_params_fn(current_step, make_policy, inference_params())
+        if dist is not None:
+            dist.barrier()
+
+    total_steps = current_step
+    assert total_steps >= num_timesteps
+    # replicas must still be identical (train.py:485-487)
+    if dist is not None:
+        ref = training_state.params.detach().clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, training_state.params.detach()), "parameter replicas diverged"
+        dist.barrier()
+    params = inference_params()
+    train.last_training_state = training_state  # value net / optimiser for checkpoint-resume (beyond the reference)
+    return make_policy, params, metrics
