@@ -1,0 +1,51 @@
+"""Worker for tests/test_distributed.py: 2 ranks, gloo, host simulation of the kernels.
+Each rank owns its shard of the envs; the only data-path collectives are the flat-gradient
+all-reduce (C1), the normaliser all-reduce (C2) and the parameter broadcast (C3)."""
+import functools
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import helpers as H  # noqa: E402
+from vnl_brax_imitation_amd.ppo_imitation import ppo_networks  # noqa: E402
+from vnl_brax_imitation_amd.ppo_imitation import train as ppo  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    env = H.hostsim_env(4)  # per-rank shard of num_envs = 4 * world
+    nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=8,
+                           encoder_layer_sizes=(16,), decoder_layer_sizes=(16,), value_hidden_layer_sizes=(16,))
+    calls = {"allreduce": 0}
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls["allreduce"] += 1
+        return orig(t, *a, **k)
+
+    dist.all_reduce = counting
+    make_policy, params, metrics = ppo.train(
+        environment=env, num_timesteps=4 * world * 4 * 2, episode_length=150, num_envs=4 * world, learning_rate=1e-3,
+        entropy_cost=1e-3, discounting=0.99, unroll_length=4, batch_size=2 * world, num_minibatches=2,
+        num_updates_per_batch=2, num_evals=1, normalize_observations=True, network_factory=nf, num_eval_envs=0,
+        eval_env=None, kl_weight=1e-4)
+    dist.all_reduce = orig
+    norm, flat = params
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    out = dict(rank=rank, identical=all(torch.equal(g, gathered[0]) for g in gathered), count=float(norm.count),
+               allreduce=calls["allreduce"], sps=metrics.get("training/sps", 0.0), nparam=int(flat.numel()))
+    print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+"""N>1 path on CPU: world_size 2, gloo.  Covers the collectives the GPU path issues over
+RCCL: one flat-gradient all-reduce per minibatch step, 3 tiny all-reduces per training step for the
+normaliser, parameter broadcast at init, replica identity at the end."""
+import json
+import os
+import subprocess
+import sys
+
+import helpers as H
+
+
+def test_two_rank_training_keeps_replicas_identical():
+    H.build_hostsim("float")  # build once, before the ranks race for it
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(H.ROOT, "tests", "dist_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = [json.loads(line.split("RESULT ", 1)[1]) for line in p.stdout.splitlines() if "RESULT " in line]
+    assert len(res) == 2
+    for r in res:
+        assert r["identical"]
+        # normaliser saw the GLOBAL batch: 2 training steps x 8 envs x 4 steps
+        assert r["count"] == 2 * 8 * 4
+        # per training step: 3 normaliser all-reduces + num_updates(2) x num_minibatches(2) gradient all-reduces
+        assert r["allreduce"] == 2 * (3 + 2 * 2)

@@ -32,6 +32,21 @@
 #define VNL_WAVE_ANY(x) (__ballot(x) != 0ull)
 #endif
 
+// Diagnostic build only (-DVNL_PROFILE, csrc/build.py --profile): per-stage s_memtime stamps summed
+// into a __device__ array that no product code reads.  Never defined in the shipped library.
+#ifdef VNL_PROFILE
+#define VNL_NPROF 16
+__device__ unsigned long long g_vnl_prof[VNL_NPROF];
+#define VNL_PROF(i)                                             \
+  do {                                                          \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    prof_[i] += t_ - last_;                                     \
+    last_ = __builtin_amdgcn_s_memtime();                       \
+  } while (0)
+#else
+#define VNL_PROF(i)
+#endif
+
 #define VNL_MINVAL vreal(1e-15)
 #define VNL_MINIMP vreal(0.0001)
 #define VNL_MAXIMP vreal(0.9999)
@@ -91,6 +106,17 @@ struct EnvLane {
   const WsLayout& L;
   vreal* ws;
   unsigned B, e;
+#ifdef VNL_PROFILE
+  mutable unsigned long long prof_[VNL_NPROF] = {0}, last_ = 0;
+  VNL_HD void prof_begin() const { last_ = __builtin_amdgcn_s_memtime(); }
+  VNL_HD void prof_end() const {
+    if ((threadIdx.x & 63) == 0)
+      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], prof_[i]);
+  }
+#else
+  VNL_HD void prof_begin() const {}
+  VNL_HD void prof_end() const {}
+#endif
 
   VNL_HD vreal& W(int o) const { return ws[(unsigned)o * B + e]; }
   VNL_HD static vreal& at(vreal* p, int k, unsigned B, unsigned e) { return p[(unsigned)k * B + e]; }
@@ -611,6 +637,7 @@ struct EnvLane {
     }
     solve_inplace(L.Mgrad);
     for (int d = 0; d < nv; d++) W(L.search + d) = -W(L.Mgrad + d);
+    VNL_PROF(6);
 
     bool done = false;
     for (int it = 0; it < m.iterations; it++) {
@@ -632,6 +659,7 @@ struct EnvLane {
         qg2 += s * W(L.mv + d);
       }
       qg2 *= vreal(0.5);
+      VNL_PROF(7);
       LsPoint p0, lo, hi;
       vreal a1[1] = {vreal(0.)};
       ls_eval<1>(a1, gauss, qg1, qg2, &p0);
@@ -667,6 +695,7 @@ struct EnvLane {
         W(L.Ma + d) += alpha * W(L.mv + d);
       }
       for (int r = 0; r < ne; r++) W(L.Jaref + r) += alpha * W(L.jv + r);
+      VNL_PROF(8);
       // ---- constraint + gradient update
       vreal gp = vdot(L.grad, L.Mgrad);
       vreal g = vreal(0.);
@@ -679,7 +708,9 @@ struct EnvLane {
         d1 += gn * W(L.Mgrad + d);
         W(L.grad + d) = gn, W(L.tmp + d) = gn;
       }
+      VNL_PROF(9);
       solve_inplace(L.tmp);
+      VNL_PROF(10);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
       for (int d = 0; d < nv; d++) {
@@ -694,11 +725,17 @@ struct EnvLane {
   // forward.forward
   VNL_HD void forward() const {
     kinematics();
+    VNL_PROF(0);
     crb_mass_matrix();
+    VNL_PROF(1);
     factor(vreal(0.));
+    VNL_PROF(2);
     bias_forces();
+    VNL_PROF(3);
     smooth_forces();
+    VNL_PROF(4);
     make_constraint();
+    VNL_PROF(5);
     solve();
   }
 
@@ -706,8 +743,10 @@ struct EnvLane {
   VNL_HD void euler() const {
     const int nv = m.nv;
     for (int d = 0; d < nv; d++) W(L.tmp + d) = m.eulerdamp ? W(L.smooth + d) + W(L.qfrc_c + d) : W(L.qacc + d);
+    VNL_PROF(11);
     if (m.eulerdamp) {
       factor(m.dt);
+      VNL_PROF(12);
       solve_inplace(L.tmp);
     }
     for (int i = 0; i < m.nu; i++)
@@ -731,6 +770,7 @@ struct EnvLane {
         ST(qpos, qa) += m.dt * ST(qvel, da);
       }
     }
+    VNL_PROF(13);
   }
 
   // ------------------------------------------------------------------ env glue
@@ -852,6 +892,7 @@ struct EnvLane {
 
   // RodentTracking.step, rodent.py:178-239
   VNL_HD void step(const vreal* action) const {
+    prof_begin();
     int clip = st.clip_id[e], old_frame = st.cur_frame[e];
     // rtrunk from the OLD pipeline state and OLD frame (rodent.py:250-262, 296)
     vreal rtrunk = termination(clip, old_frame);
@@ -917,6 +958,8 @@ struct EnvLane {
     ST(metrics, 4) = ract, ST(metrics, 5) = rapp, ST(metrics, 6) = rtrunk;
     st.cur_frame[e] = new_frame, st.sub_clip_frame[e] = new_sub;
     st.term_err[e] = rtrunk;
+    VNL_PROF(14);
+    prof_end();
   }
 #undef ST
 };

@@ -453,5 +453,15 @@ extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* 
   return VNL_OK;
 }
 
+#ifdef VNL_PROFILE
+// diagnostic build only: read and clear the per-stage cycle sums
+extern "C" int vnl_prof_read(unsigned long long* out) {
+  unsigned long long z[VNL_NPROF] = {0};
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vnl_prof), sizeof(z)));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vnl_prof), z, sizeof(z)));
+  return VNL_OK;
+}
+#endif
+
 // ----------------------------------------------------------------------------- policy
 #include "vnl_policy_impl.h"
