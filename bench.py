@@ -91,7 +91,7 @@ def main() -> None:
     gen.manual_seed(1234 + rank)  # independent stream per rank: envs shard, nothing crosses the links
     state = env.reset(gen)
     total = args.steps + args.warmup
-    actions = torch.clamp(0.3 * torch.randn((total, 30, B), generator=gen), -1.0, 1.0).to(dev)  # SoA per step
+    actions = torch.clamp(0.3 * torch.randn((total, B, 30), generator=gen), -1.0, 1.0).to(dev)
     torch.cuda.synchronize(dev)
 
     for k in range(args.warmup):

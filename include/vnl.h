@@ -15,9 +15,10 @@
  * Conventions
  *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
  *   - every state / observation / action buffer is CALLER-OWNED device memory,
- *     float32 (int32 for frame counters), laid out structure-of-arrays
- *     [feature][env] with env stride = num_envs (lane e of a wavefront touches
- *     element feature*num_envs + e: one coalesced 256-B line per wave access);
+ *     float32 (int32 for frame counters), row-major [env][feature] (what a
+ *     torch (B, n) tensor is).  One 64-lane wavefront owns one env, so lane i
+ *     touches element env*n + i: contiguous per wave, and obs/traj come out in
+ *     the layout the policy GEMMs consume;
  *   - the library owns model constants, the clip copy and per-env scratch,
  *     released by vnl_env_destroy / vnl_model_destroy;
  *   - all work is enqueued asynchronously on the caller's HIP stream (passed as
@@ -84,7 +85,7 @@ typedef struct vnl_envspec {
   const float* joints_velocity;  /* (C,T,nq-7) */
 } vnl_envspec;
 
-/* Caller-owned device buffers, SoA [feature][num_envs]. */
+/* Caller-owned device buffers, row-major [num_envs][count]. */
 typedef struct vnl_state {
   /* brax State.pipeline_state (mjx.Data) -- carried */
   float* qpos;           /* [nq] */
@@ -128,22 +129,24 @@ void vnl_env_destroy(vnl_env*);
 int vnl_env_dims(const vnl_env*, vnl_dims* out);
 
 /* reset: start_frame [num_envs] int32, clip_id written by caller into state->clip_id,
- * noise SoA [nq][num_envs] (already scaled by reset_noise_scale; rodent.py:131-147). */
+ * noise [num_envs][nq] (already scaled by reset_noise_scale; rodent.py:131-147). */
 int vnl_env_reset(vnl_env*, const int32_t* start_frame, const float* noise, const vnl_state* state, void* stream);
 
-/* step: action SoA [nu][num_envs]; state updated in place. */
+/* step: action [num_envs][nu]; state updated in place. */
 int vnl_env_step(vnl_env*, const float* action, const vnl_state* state, void* stream);
 
-/* Bisection hook: device pointer + element count (per env) of a named scratch
- * section as left by the last reset/step ("qM", "qLD", "qfrc_smooth", "qacc_smooth",
- * "qacc", "efc_D", "efc_aref", "con_dist", ...).  Layout SoA [count][num_envs]. */
+/* Bisection hooks.  The per-env working set lives in LDS; with debug on, every reset/step
+ * also copies it to a device dump [num_envs][row_stride].  vnl_env_scratch returns the device
+ * pointer of a named section inside row 0 ("qLD", "qfrc_smooth", "qacc_smooth", "qacc",
+ * "efc_D", "efc_aref", "con_dist", ...) and its element count; env e is at +e*row_stride. */
+int vnl_env_debug(vnl_env*, int32_t enable, int32_t* row_stride);
 int vnl_env_scratch(const vnl_env*, const char* name, float** dev_ptr, int32_t* count);
 
 /* ---- policy forward (intention network), ppo_networks.py:45-83 ----------------
  * params: flat float32 device buffer in the order documented in INTEGRATION.md.
- * Inputs traj/obs SoA as produced by vnl_env_step; normaliser mean/std [obs_size].
- * eps_latent [latent][B] and eps_action [act][B] are caller-supplied N(0,1) draws
- * (the JAX threefry stream is not reproduced).  Outputs SoA. */
+ * Inputs traj/obs row-major as produced by vnl_env_step; normaliser mean/std [obs_size].
+ * eps_latent [B][latent] and eps_action [B][act] are caller-supplied N(0,1) draws
+ * (the JAX threefry stream is not reproduced).  Outputs row-major. */
 typedef struct vnl_policy_spec {
   int32_t traj_size, obs_size, action_size, latent_size;
   int32_t num_encoder_layers, num_decoder_layers;

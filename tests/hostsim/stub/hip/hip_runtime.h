@@ -31,14 +31,24 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-#define VNL_WAVE_ANY(x) (x)
+// Fork-join primitives of csrc/vnl_body.h, host flavour: one pass per workgroup in which every
+// parallel-for region simply runs over all its items, serial regions run once, and cross-lane
+// reductions are the identity (the single pass has already accumulated every item).
+#define VNL_FORKJOIN_DEFINED
+#define VNL_HD inline
+#define VNL_LANES 1
+#define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
+#define VNL_SERIAL if (true)
+#define VNL_SYNC()
+#define VNL_LDS_DECL(name) static thread_local vreal name[32768]
+#define vnl_wave_sum(x) (x)
+#define vnl_wave_any(x) (x)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
   do {                                                                         \
     dim3 g_ = (grid), b_ = (block);                                            \
     gridDim = g_, blockDim = b_;                                               \
-    for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                  \
-      for (unsigned tx_ = 0; tx_ < b_.x; tx_++) {                              \
-        blockIdx = dim3(bx_), threadIdx = dim3(tx_);                           \
-        kernel(__VA_ARGS__);                                                   \
-      }                                                                        \
+    for (unsigned bx_ = 0; bx_ < g_.x; bx_++) {                                \
+      blockIdx = dim3(bx_), threadIdx = dim3(0);                               \
+      kernel(__VA_ARGS__);                                                     \
+    }                                                                          \
   } while (0)

@@ -74,7 +74,7 @@ class PolicySpec(C.Structure):
 
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
-    "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
+    "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
     "vnl_policy_num_params", "vnl_policy_forward",
 )
 
@@ -96,6 +96,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_dims.argtypes = [vp, C.POINTER(Dims)]
     lib.vnl_env_reset.argtypes = [vp, vp, vp, C.POINTER(StatePtrs), vp]
     lib.vnl_env_step.argtypes = [vp, vp, C.POINTER(StatePtrs), vp]
+    lib.vnl_env_debug.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.vnl_policy_destroy.argtypes = [vp]

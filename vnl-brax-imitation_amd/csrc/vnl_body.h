@@ -1,35 +1,64 @@
-// One environment per wavefront lane: the whole control step (n_frames physics
-// substeps + observation / reference-trajectory / reward / termination glue) as
-// straight per-lane code.  Control flow is wave-uniform (same model for every
-// lane); table indices are scalars; all per-env storage is SoA [idx][env] so each
-// wave access is one coalesced 256-B line.
+// One environment per wavefront, all per-env state resident in LDS.
+//
+// A 64-lane workgroup owns one env for a whole control step (n_frames physics substeps +
+// observation / reference-trajectory / reward / termination glue).  The code is fork-join
+// over the wave:
+//     VNL_FOR(i, n)  { ... }   parallel-for over the 64 lanes (rows, matrix entries, bodies,
+//                              contacts, dofs), followed by VNL_SYNC()
+//     VNL_SERIAL     { ... }   one lane walks the kinematic tree (parent -> child chains)
+//     wave_sum(x)              cross-lane reduction; scalars derived from it are wave-uniform
+// Every array that crosses a region lives in LDS (`s[...]`, ~25 KB per env, 6 envs per CU);
+// HBM is touched only to load the carried state and to store the new state / obs / traj, with
+// row-major [env][feature] buffers so those accesses are contiguous per wave.
 //
 // What each stage follows:
-//   physics  : MJX forward/step [UPSTREAM mjx/_src/{smooth,collision_primitive,
-//              constraint,solver,passive,forward}.py], called from reference
-//              envs/rodent.py:148 (pipeline_init) and :181 (pipeline_step)
+//   physics  : MJX forward/step [UPSTREAM mjx/_src/{smooth,collision_primitive,constraint,
+//              solver,passive,forward}.py], called from reference envs/rodent.py:148
+//              (pipeline_init) and :181 (pipeline_step)
 //   env glue : reference envs/rodent.py:178-470
 //
-// Algorithmic choices that differ from MJX's dense route (same mathematics):
-//   * spatial quantities (cdof, cinert, cvel ...) are expressed about the root
-//     body's origin O instead of subtree_com[root]; the choice of reference point
-//     cancels in every scalar the step produces;
-//   * qM is kept tree-sparse (MuJoCo's dof_Madr layout, 1119 entries for the
-//     rodent) and factorised as L'DL (mj_factorM order) instead of dense Cholesky;
-//   * efc_J is never materialised: J*v and J'*f are evaluated through the
-//     kinematic tree (body twist forward pass / body wrench backward pass);
-//   * M*v is evaluated matrix-free with the per-body inertias and shares the
-//     forward pass of J*v.
+// Algorithmic choices that differ from MJX's dense route (same mathematics; checked against
+// the dense float64 oracle by the float64 host build, tests/test_hostsim_parity.py):
+//   * spatial quantities (cdof, cinert, cvel ...) are expressed about the root body's origin
+//     O instead of subtree_com[root]; the reference point cancels in every scalar produced;
+//   * qM is built tree-sparse (MuJoCo's dof_Madr layout, 1119 entries for the rodent) directly
+//     into the factor buffer and factorised in place as L'DL (mj_factorM order);
+//   * efc_J is never materialised: J*v and J'*f go through the kinematic tree (body twists
+//     forward / body wrenches backward);
+//   * inside the CG loop M*search is carried by the recurrence M s_new = -grad + beta * M s_old
+//     (search = -M^-1 grad + beta search); the only explicit product, M*qacc_warmstart, uses
+//     the factor (L' D L).
 #pragma once
 #include <math.h>
 
 #include "vnl_types.h"
 
 #ifndef VNL_HD
-#define VNL_HD __host__ __device__ __forceinline__
+#define VNL_HD __device__ __forceinline__
 #endif
-#ifndef VNL_WAVE_ANY
-#define VNL_WAVE_ANY(x) (__ballot(x) != 0ull)
+
+// ---- fork-join primitives (the host simulation in tests/hostsim redefines them) ------------
+#ifndef VNL_FORKJOIN_DEFINED
+#define VNL_LANES 64
+#define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
+#define VNL_SERIAL if (lane == 0)
+#define VNL_SYNC() __syncthreads()
+#define VNL_LDS_DECL(name) extern __shared__ __align__(16) vreal name[]
+// Cross-lane sum with DPP (VALU-rate) instead of ds_bpermute: xor-butterfly inside each row of 16
+// lanes (quad_perm, row_half_mirror, row_mirror), then the four row totals through v_readlane.
+// Every lane returns the same value.
+VNL_HD float vnl_wave_sum(float x) {
+#define VNL_DPP_STEP(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  VNL_DPP_STEP(0xB1);   // quad_perm [1,0,3,2]
+  VNL_DPP_STEP(0x4E);   // quad_perm [2,3,0,1]
+  VNL_DPP_STEP(0x141);  // row_half_mirror
+  VNL_DPP_STEP(0x140);  // row_mirror
+#undef VNL_DPP_STEP
+  int xi = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+}
+VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
 #endif
 
 // Diagnostic build only (-DVNL_PROFILE, csrc/build.py --profile): per-stage s_memtime stamps summed
@@ -37,11 +66,11 @@
 #ifdef VNL_PROFILE
 #define VNL_NPROF 16
 __device__ unsigned long long g_vnl_prof[VNL_NPROF];
-#define VNL_PROF(i)                                             \
-  do {                                                          \
-    unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
-    prof_[i] += t_ - last_;                                     \
-    last_ = __builtin_amdgcn_s_memtime();                       \
+#define VNL_PROF(i)                                       \
+  do {                                                    \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    prof_[i] += t_ - last_;                               \
+    last_ = __builtin_amdgcn_s_memtime();                 \
   } while (0)
 #else
 #define VNL_PROF(i)
@@ -99,18 +128,18 @@ VNL_HD vreal dot(S6 p, S6 q) { return dot(p.a, q.a) + dot(p.l, q.l); }
 VNL_HD S6 mcross(S6 u, S6 v) { return S6{cross(u.a, v.a), cross(u.l, v.a) + cross(u.a, v.l)}; }
 VNL_HD S6 mcross_force(S6 v, S6 f) { return S6{cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
 
-struct EnvLane {
+struct EnvWave {
   const DevModel& m;
   const DevEnv& ev;
   const DevState& st;
   const WsLayout& L;
-  vreal* ws;
-  unsigned B, e;
+  vreal* s;  // LDS
+  unsigned e, lane;
 #ifdef VNL_PROFILE
   mutable unsigned long long prof_[VNL_NPROF] = {0}, last_ = 0;
   VNL_HD void prof_begin() const { last_ = __builtin_amdgcn_s_memtime(); }
   VNL_HD void prof_end() const {
-    if ((threadIdx.x & 63) == 0)
+    if (lane == 0)
       for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], prof_[i]);
   }
 #else
@@ -118,12 +147,9 @@ struct EnvLane {
   VNL_HD void prof_end() const {}
 #endif
 
-  VNL_HD vreal& W(int o) const { return ws[(unsigned)o * B + e]; }
-  VNL_HD static vreal& at(vreal* p, int k, unsigned B, unsigned e) { return p[(unsigned)k * B + e]; }
-#define ST(field, k) st.field[(unsigned)(k)*B + e]
-
-  VNL_HD V3 ld3(int o) const { return V3{W(o), W(o + 1), W(o + 2)}; }
-  VNL_HD void st3(int o, V3 v) const { W(o) = v.x, W(o + 1) = v.y, W(o + 2) = v.z; }
+  VNL_HD V3 ld3(int o) const { return V3{s[o], s[o + 1], s[o + 2]}; }
+  VNL_HD void st3(int o, V3 v) const { s[o] = v.x, s[o + 1] = v.y, s[o + 2] = v.z; }
+  VNL_HD Q4 ld4(int o) const { return Q4{s[o], s[o + 1], s[o + 2], s[o + 3]}; }
   VNL_HD S6 ld6(int o) const { return S6{ld3(o), ld3(o + 3)}; }
   VNL_HD void st6(int o, S6 v) const { st3(o, v.a), st3(o + 3, v.l); }
   VNL_HD static V3 t3(const vreal* t, int i) { return V3{t[3 * i], t[3 * i + 1], t[3 * i + 2]}; }
@@ -131,9 +157,9 @@ struct EnvLane {
 
   // cinert (10) x motion -> force   [MJX math.inert_mul]
   VNL_HD S6 inert_mul(int o, S6 v) const {
-    vreal ixx = W(o), iyy = W(o + 1), izz = W(o + 2), ixy = W(o + 3), ixz = W(o + 4), iyz = W(o + 5);
+    vreal ixx = s[o], iyy = s[o + 1], izz = s[o + 2], ixy = s[o + 3], ixz = s[o + 4], iyz = s[o + 5];
     V3 mp = ld3(o + 6);
-    vreal mass = W(o + 9);
+    vreal mass = s[o + 9];
     V3 ang = V3{ixx * v.a.x + ixy * v.a.y + ixz * v.a.z, ixy * v.a.x + iyy * v.a.y + iyz * v.a.z,
                 ixz * v.a.x + iyz * v.a.y + izz * v.a.z} +
              cross(mp, v.l);
@@ -141,63 +167,101 @@ struct EnvLane {
     return S6{ang, lin};
   }
 
-  // ------------------------------------------------------------------ kinematics
-  // smooth.kinematics + com_pos (cdof, cinert) in one tree pass, reference point O.
-  VNL_HD V3 ref_point() const {
-    return m.root_free ? V3{ST(qpos, 0), ST(qpos, 1), ST(qpos, 2)} : V3{m.root_px, m.root_py, m.root_pz};
+  VNL_HD V3 ref_point() const { return m.root_free ? ld3(L.qpos) : V3{m.root_px, m.root_py, m.root_pz}; }
+
+  // ---- small index tables staged in LDS (dependent lookups in the sparse linear algebra and in the
+  // tree walks would otherwise each pay a global / scalar-cache round trip)
+  VNL_HD int anc_of(int k) const { return ((const unsigned char*)(s + L.tab_anc))[k]; }  // column dof of entry k
+  VNL_HD int madr(int d) const { return ((const int*)(s + L.tab_madr))[d]; }              // first entry of row d
+  VNL_HD int eadr(int d) const { return ((const int*)(s + L.tab_E))[d]; }                 // madr(d) + depth(d)
+  VNL_HD int depth(int d) const { return eadr(d) - madr(d); }
+  VNL_HD int parent_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[b]; }
+  VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
+  VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
+  VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + c]; }
+  VNL_HD void load_tables() const {
+    unsigned char* ta = (unsigned char*)(s + L.tab_anc);
+    VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
+    int* tm = (int*)(s + L.tab_madr);
+    int* te = (int*)(s + L.tab_E);
+    VNL_FOR(d, m.nv) tm[d] = m.dof_Madr[d], te[d] = m.dof_Madr[d] + m.dof_depth[d];
+    unsigned char* tb = (unsigned char*)(s + L.tab_body);
+    VNL_FOR(b, m.nbody) {
+      tb[b] = (unsigned char)m.body_parent[b];
+      tb[m.nbody + b] = (unsigned char)m.body_dofadr[b];
+      tb[2 * m.nbody + b] = (unsigned char)m.body_dofnum[b];
+    }
+    VNL_FOR(c, m.ncon) tb[3 * m.nbody + c] = (unsigned char)m.cg_body[m.con_geom[c]];
+    VNL_SYNC();
   }
 
+  // ------------------------------------------------------------------ kinematics
+  // smooth.kinematics + cdof in one tree walk (one lane), reference point O.
   VNL_HD void kinematics() const {
-    V3 O = ref_point();
-    ST(xpos, 0) = vreal(0.), ST(xpos, 1) = vreal(0.), ST(xpos, 2) = vreal(0.);
-    ST(xquat, 0) = vreal(1.), ST(xquat, 1) = vreal(0.), ST(xquat, 2) = vreal(0.), ST(xquat, 3) = vreal(0.);
-    for (int k = 0; k < 10; k++) W(L.cinert + k) = vreal(0.);
-    V3 csum = v3(vreal(0.), vreal(0.), vreal(0.));
-    for (int b = 1; b < m.nbody; b++) {
-      int p = m.body_parent[b];
-      V3 ppos = V3{ST(xpos, 3 * p), ST(xpos, 3 * p + 1), ST(xpos, 3 * p + 2)};
-      Q4 pq = Q4{ST(xquat, 4 * p), ST(xquat, 4 * p + 1), ST(xquat, 4 * p + 2), ST(xquat, 4 * p + 3)};
-      V3 pos = ppos + qrot(t3(m.body_pos, b), pq);
-      Q4 quat = qmul(pq, t4(m.body_quat, b));
-      int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
-      for (int k = 0; k < jn; k++) {
-        int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-        if (m.jnt_type[j] == VNL_JNT_FREE) {
-          pos = V3{ST(qpos, qa), ST(qpos, qa + 1), ST(qpos, qa + 2)};
-          quat = Q4{ST(qpos, qa + 3), ST(qpos, qa + 4), ST(qpos, qa + 5), ST(qpos, qa + 6)};
-          vreal n = sqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
-          vreal inv = n > vreal(0.) ? vreal(1.) / n : vreal(1.);
-          quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
-          ST(qpos, qa + 3) = quat.w, ST(qpos, qa + 4) = quat.x, ST(qpos, qa + 5) = quat.y, ST(qpos, qa + 6) = quat.z;
-          M3 R = qmat(quat);
-          V3 off = O - pos;
-          for (int t = 0; t < 3; t++) {
-            int o = L.cdof + 6 * (da + t);
-            W(o) = vreal(0.), W(o + 1) = vreal(0.), W(o + 2) = vreal(0.);
-            W(o + 3) = t == 0 ? vreal(1.) : vreal(0.), W(o + 4) = t == 1 ? vreal(1.) : vreal(0.), W(o + 5) = t == 2 ? vreal(1.) : vreal(0.);
+    VNL_SERIAL {
+      V3 O = ref_point();
+      st3(L.xpos, v3(vreal(0.), vreal(0.), vreal(0.)));
+      s[L.xquat] = vreal(1.), s[L.xquat + 1] = vreal(0.), s[L.xquat + 2] = vreal(0.), s[L.xquat + 3] = vreal(0.);
+      for (int b = 1; b < m.nbody; b++) {
+        int p = m.body_parent[b];
+        Q4 pq = ld4(L.xquat + 4 * p);
+        V3 pos = ld3(L.xpos + 3 * p) + qrot(t3(m.body_pos, b), pq);
+        Q4 quat = qmul(pq, t4(m.body_quat, b));
+        int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+        for (int k = 0; k < jn; k++) {
+          int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+          if (m.jnt_type[j] == VNL_JNT_FREE) {
+            pos = ld3(L.qpos + qa);
+            quat = ld4(L.qpos + qa + 3);
+            vreal n = sqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
+            vreal inv = n > vreal(0.) ? vreal(1.) / n : vreal(1.);
+            quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
+            s[L.qpos + qa + 3] = quat.w, s[L.qpos + qa + 4] = quat.x, s[L.qpos + qa + 5] = quat.y,
+                            s[L.qpos + qa + 6] = quat.z;  // normalised quaternion written back
+            M3 R = qmat(quat);
+            V3 off = O - pos;
+            for (int t = 0; t < 3; t++) {
+              int o = L.cdof + 6 * (da + t);
+              s[o] = vreal(0.), s[o + 1] = vreal(0.), s[o + 2] = vreal(0.);
+              s[o + 3] = t == 0 ? vreal(1.) : vreal(0.), s[o + 4] = t == 1 ? vreal(1.) : vreal(0.),
+                    s[o + 5] = t == 2 ? vreal(1.) : vreal(0.);
+            }
+            for (int t = 0; t < 3; t++) {
+              V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
+              st6(L.cdof + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
+            }
+          } else {
+            V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
+            V3 anchor = qrot(jp, quat) + pos;
+            V3 axis = qrot(jax, quat);
+            vreal ang = s[L.qpos + qa] - m.jnt_qpos0[j];
+            vreal sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
+            quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+            pos = anchor - qrot(jp, quat);
+            st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
           }
-          for (int t = 0; t < 3; t++) {
-            V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
-            st6(L.cdof + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
-          }
-        } else {
-          V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
-          V3 anchor = qrot(jp, quat) + pos;
-          V3 axis = qrot(jax, quat);
-          vreal ang = ST(qpos, qa) - m.jnt_qpos0[j];
-          vreal s = sin(vreal(0.5) * ang), c = cos(vreal(0.5) * ang);
-          quat = qmul(quat, Q4{c, jax.x * s, jax.y * s, jax.z * s});
-          pos = anchor - qrot(jp, quat);
-          st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
         }
+        st3(L.xpos + 3 * b, pos);
+        s[L.xquat + 4 * b] = quat.w, s[L.xquat + 4 * b + 1] = quat.x, s[L.xquat + 4 * b + 2] = quat.y,
+                        s[L.xquat + 4 * b + 3] = quat.z;
       }
-      ST(xpos, 3 * b) = pos.x, ST(xpos, 3 * b + 1) = pos.y, ST(xpos, 3 * b + 2) = pos.z;
-      ST(xquat, 4 * b) = quat.w, ST(xquat, 4 * b + 1) = quat.x, ST(xquat, 4 * b + 2) = quat.y,
-                    ST(xquat, 4 * b + 3) = quat.z;
-      // inertia about O in world axes: R I R' + m(|r|^2 1 - r r'), r = xipos - O
-      M3 R = qmat(quat);
+    }
+    VNL_SYNC();
+  }
+
+  // com_pos: cinert about O in world axes, R I R' + m(|r|^2 1 - r r'), r = xipos - O -> T1; optionally com
+  VNL_HD void body_inertias(bool with_com) const {
+    V3 O = ref_point();
+    V3 csum = v3(vreal(0.), vreal(0.), vreal(0.));
+    VNL_FOR(b, m.nbody) {
+      int o = L.T1 + 10 * b;
+      if (b == 0) {
+        for (int k = 0; k < 10; k++) s[o + k] = vreal(0.);
+        continue;
+      }
+      M3 R = qmat(ld4(L.xquat + 4 * b));
       vreal mass = m.body_mass[b];
-      V3 xip = pos + mmul(R, t3(m.body_ipos, b));
+      V3 xip = ld3(L.xpos + 3 * b) + mmul(R, t3(m.body_ipos, b));
       csum = csum + xip * mass;
       V3 r = xip - O;
       const vreal* I6 = m.body_inertia6 + 6 * b;  // xx yy zz xy xz yz (body axes, about ipos)
@@ -207,141 +271,214 @@ struct EnvLane {
         for (int k = 0; k < 3; k++)
           T[3 * i + k] = R.a[3 * i] * Ib[k] + R.a[3 * i + 1] * Ib[3 + k] + R.a[3 * i + 2] * Ib[6 + k];
       vreal rr = dot(r, r);
-      int o = L.cinert + 10 * b;
-      W(o + 0) = T[0] * R.a[0] + T[1] * R.a[1] + T[2] * R.a[2] + mass * (rr - r.x * r.x);
-      W(o + 1) = T[3] * R.a[3] + T[4] * R.a[4] + T[5] * R.a[5] + mass * (rr - r.y * r.y);
-      W(o + 2) = T[6] * R.a[6] + T[7] * R.a[7] + T[8] * R.a[8] + mass * (rr - r.z * r.z);
-      W(o + 3) = T[0] * R.a[3] + T[1] * R.a[4] + T[2] * R.a[5] - mass * r.x * r.y;
-      W(o + 4) = T[0] * R.a[6] + T[1] * R.a[7] + T[2] * R.a[8] - mass * r.x * r.z;
-      W(o + 5) = T[3] * R.a[6] + T[4] * R.a[7] + T[5] * R.a[8] - mass * r.y * r.z;
-      W(o + 6) = r.x * mass, W(o + 7) = r.y * mass, W(o + 8) = r.z * mass, W(o + 9) = mass;
+      s[o + 0] = T[0] * R.a[0] + T[1] * R.a[1] + T[2] * R.a[2] + mass * (rr - r.x * r.x);
+      s[o + 1] = T[3] * R.a[3] + T[4] * R.a[4] + T[5] * R.a[5] + mass * (rr - r.y * r.y);
+      s[o + 2] = T[6] * R.a[6] + T[7] * R.a[7] + T[8] * R.a[8] + mass * (rr - r.z * r.z);
+      s[o + 3] = T[0] * R.a[3] + T[1] * R.a[4] + T[2] * R.a[5] - mass * r.x * r.y;
+      s[o + 4] = T[0] * R.a[6] + T[1] * R.a[7] + T[2] * R.a[8] - mass * r.x * r.z;
+      s[o + 5] = T[3] * R.a[6] + T[4] * R.a[7] + T[5] * R.a[8] - mass * r.y * r.z;
+      s[o + 6] = r.x * mass, s[o + 7] = r.y * mass, s[o + 8] = r.z * mass, s[o + 9] = mass;
     }
-    ST(com1, 0) = csum.x * m.total_mass_inv, ST(com1, 1) = csum.y * m.total_mass_inv,
-             ST(com1, 2) = csum.z * m.total_mass_inv;
+    if (with_com) {
+      vreal cx = vnl_wave_sum(csum.x), cy = vnl_wave_sum(csum.y), cz = vnl_wave_sum(csum.z);
+      VNL_SERIAL { st3(L.com, v3(cx * m.total_mass_inv, cy * m.total_mass_inv, cz * m.total_mass_inv)); }
+    }
+    VNL_SYNC();
+  }
+
+  // sum children into parents, one lane per component (serial over bodies within a lane)
+  VNL_HD void tree_accumulate(int base, int width) const {
+    VNL_FOR(k, width) {
+      for (int b = m.nbody - 1; b > 1; b--) {
+        int p = parent_of(b);
+        if (p > 0) s[base + width * p + k] += s[base + width * b + k];
+      }
+    }
+    VNL_SYNC();
   }
 
   // ------------------------------------------------------------------ inertia
-  // smooth.crb + make_m into the tree-sparse layout: row i = [M(i,i), M(i,anc1), ...]
-  VNL_HD void crb_mass_matrix() const {
-    int n10 = 10 * m.nbody;
-    for (int k = 0; k < n10; k++) W(L.bodyA + k) = W(L.cinert + k);
-    for (int b = m.nbody - 1; b > 1; b--) {
-      int p = m.body_parent[b];
-      if (p > 0)
-        for (int k = 0; k < 10; k++) W(L.bodyA + 10 * p + k) += W(L.bodyA + 10 * b + k);
+  // smooth.crb + make_m straight into the factor buffer: LD <- qM + diag_scale * diag(damping).
+  // Expects cinert in T1 (turned into crb in place).
+  VNL_HD void mass_matrix(vreal diag_scale) const {
+    tree_accumulate(L.T1, 10);
+    int F = L.T2 + 6 * m.nbody;  // per-dof crb * cdof
+    VNL_FOR(i, m.nv) st6(F + 6 * i, inert_mul(L.T1 + 10 * m.dof_body[i], ld6(L.cdof + 6 * i)));
+    VNL_SYNC();
+    VNL_FOR(k, m.nM) {
+      int i = m.M_row[k], j = m.M_anc[k];
+      vreal v = dot(ld6(F + 6 * i), ld6(L.cdof + 6 * j));
+      if (i == j) v += m.dof_armature[i] + diag_scale * m.dof_damping[i];
+      s[L.LD + k] = v;
     }
-    for (int i = 0; i < m.nv; i++) {
-      S6 f = inert_mul(L.bodyA + 10 * m.dof_body[i], ld6(L.cdof + 6 * i));
-      int adr = m.dof_Madr[i], dep = m.dof_depth[i];
-      for (int a = 0; a <= dep; a++) {
-        int j = m.M_anc[adr + a];
-        vreal v = dot(f, ld6(L.cdof + 6 * j));
-        if (a == 0) v += m.dof_armature[i];
-        W(L.M + adr + a) = v;
-      }
-    }
+    VNL_SYNC();
   }
 
-  // L'DL of (M + diag_scale*damping) in MuJoCo's mj_factorM order -> LD, dinv
-  VNL_HD void factor(vreal diag_scale) const {
-    for (int k = 0; k < m.nM; k++) W(L.LD + k) = W(L.M + k);
-    if (diag_scale != vreal(0.))
-      for (int i = 0; i < m.nv; i++) W(L.LD + m.dof_Madr[i]) += diag_scale * m.dof_damping[i];
+  // In-place L'DL in MuJoCo's mj_factorM order.  For a fixed k the rows that get updated are the
+  // (distinct) ancestors of k and row k itself is only read, so all dk(dk+1)/2 multiply-adds of
+  // iteration k run in one parallel region; pair p -> (a, a+c) comes from one universal triangular
+  // table (ordered by a+c, so a prefix of it enumerates any depth).  The division of row k by its
+  // pivot is deferred to one final pass (row k is never touched again after iteration k).
+  VNL_HD void factor() const {
     for (int k = m.nv - 1; k >= 0; k--) {
-      int adr_k = m.dof_Madr[k], dk = m.dof_depth[k];
-      vreal inv = vreal(1.) / W(L.LD + adr_k);
-      W(L.dinv + k) = inv;
-      for (int a = 1; a <= dk; a++) {
-        int i = m.M_anc[adr_k + a];
-        int adr_i = m.dof_Madr[i], len = dk - a + 1;
-        vreal tmp = W(L.LD + adr_k + a) * inv;
-        for (int c = 0; c < len; c++) W(L.LD + adr_i + c) -= tmp * W(L.LD + adr_k + a + c);
-        W(L.LD + adr_k + a) = tmp;
+      int adr_k = madr(k), dk = eadr(k) - adr_k;
+      vreal inv = vreal(1.) / s[L.LD + adr_k];
+      VNL_SERIAL { s[L.dinv + k] = inv; }
+      if (dk == 0) continue;
+      int np = dk * (dk + 1) / 2;
+      VNL_FOR(p, np) {
+        int t = m.tri[p], a = t & 255, sidx = t >> 8;
+        vreal tmp = s[L.LD + adr_k + a] * inv;
+        int dst = madr(anc_of(adr_k + a)) + sidx - a;
+        s[L.LD + dst] -= tmp * s[L.LD + adr_k + sidx];
       }
+      VNL_SYNC();
+    }
+    VNL_SYNC();
+    VNL_FOR(e2, m.nM) {
+      int i = m.M_row[e2];
+      if (anc_of(e2) != i) s[L.LD + e2] *= s[L.dinv + i];
+    }
+    VNL_SYNC();
+  }
+
+  // out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]   (A = strictly-lower part held in LD: L or L^-1)
+  VNL_HD void row_apply(int in, int out, bool scale_by_dinv) const {
+    VNL_FOR(i, m.nv) {
+      int adr = madr(i), dep = eadr(i) - adr;
+      vreal acc = s[in + i];
+      for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[in + anc_of(adr + t)];
+      s[out + i] = scale_by_dinv ? acc * s[L.dinv + i] : acc;
+    }
+    VNL_SYNC();
+  }
+  // out[a] = (in[a] + sum_{i in desc(a)} A(i, a) in[i]) (* or / D); descendants are the next ndesc dofs
+  VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/) const {
+    VNL_FOR(a, m.nv) {
+      int da = eadr(a) - madr(a), nd = m.dof_ndesc[a];
+      vreal acc = s[in + a];
+      for (int i = a + 1; i <= a + nd; i++) acc += s[L.LD + eadr(i) - da] * s[in + i];
+      s[out + a] = dmode == 1 ? acc * s[L.dinv + a] : (dmode == 2 ? acc / s[L.dinv + a] : acc);
+    }
+    VNL_SYNC();
+  }
+
+  // L -> L^-1 in place (same ancestor sparsity).  N(i,t) = -L(i,t) - sum_{s<t} L(i,s) N(anc_s, t-s):
+  // rows of one depth level only need already-converted ancestor rows and their own (still L) row,
+  // so a level is computed into a staging buffer, then written back.
+  VNL_HD void invert_factor() const {
+    int stage = L.Ma;  // Ma|grad|Mgrad... are free while factorising
+    for (int lev = 1; lev <= m.max_depth; lev++) {
+      int p0 = m.lvl_ptr[lev], n = m.lvl_ptr[lev + 1] - p0;
+      VNL_FOR(q, n) {
+        int e2 = m.lvl_entry[p0 + q], i = m.M_row[e2];
+        int adr = madr(i), t = e2 - adr;
+        vreal acc = -s[L.LD + e2];
+        for (int u = 1; u < t; u++) acc -= s[L.LD + adr + u] * s[L.LD + madr(anc_of(adr + u)) + t - u];
+        s[stage + q] = acc;
+      }
+      VNL_SYNC();
+      VNL_FOR(q, n) s[L.LD + m.lvl_entry[p0 + q]] = s[stage + q];
+      VNL_SYNC();
     }
   }
 
-  // x <- (L'DL)^-1 x   [mj_solveLD]
+  // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
   VNL_HD void solve_inplace(int x) const {
-    for (int i = m.nv - 1; i >= 0; i--) {
-      int adr = m.dof_Madr[i], dep = m.dof_depth[i];
-      vreal xi = W(x + i);
-      for (int a = 1; a <= dep; a++) W(x + m.M_anc[adr + a]) -= W(L.LD + adr + a) * xi;
+    col_apply(x, L.tmp2, 1);
+    row_apply(L.tmp2, x, false);
+  }
+
+  // out = M v = L' D L v with the (not yet inverted) factor
+  VNL_HD void mass_mul_factor(int vec, int out) const {
+    VNL_FOR(i, m.nv) {
+      int adr = madr(i), dep = eadr(i) - adr;
+      vreal acc = s[vec + i];
+      for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[vec + anc_of(adr + t)];
+      s[L.tmp2 + i] = acc / s[L.dinv + i];
     }
-    for (int i = 0; i < m.nv; i++) {
-      int adr = m.dof_Madr[i], dep = m.dof_depth[i];
-      vreal s = W(x + i) * W(L.dinv + i);
-      // forward substitution needs D^-1 applied to ancestors first: ancestors have lower index, already final
-      for (int a = 1; a <= dep; a++) s -= W(L.LD + adr + a) * W(x + m.M_anc[adr + a]);
-      W(x + i) = s;
-    }
+    VNL_SYNC();
+    col_apply(L.tmp2, out, 0);
   }
 
   // ------------------------------------------------------------------ velocity
-  // com_vel + rne in one forward / one backward pass; qfrc_bias -> L.bias
+  // com_vel + rne: qfrc_bias -> L.bias.  cvel stays in T2[0 .. 6 nbody) for make_constraint.
   VNL_HD void bias_forces() const {
-    int cv = L.bodyB, ca = L.bodyB + 6 * m.nbody, cf = L.bodyC;
-    st6(cv, S6{v3(0, 0, 0), v3(0, 0, 0)});
-    st6(ca, S6{v3(0, 0, 0), v3(-m.gx, -m.gy, -m.gz)});
-    for (int b = 1; b < m.nbody; b++) {
-      int p = m.body_parent[b];
-      S6 vel = ld6(cv + 6 * p), acc = ld6(ca + 6 * p);
-      int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
-      for (int k = 0; k < jn; k++) {
-        int j = ja + k, da = m.jnt_dofadr[j];
-        if (m.jnt_type[j] == VNL_JNT_FREE) {
-          for (int t = 0; t < 3; t++) vel = vel + ld6(L.cdof + 6 * (da + t)) * ST(qvel, da + t);
-          S6 vel0 = vel;
-          for (int t = 3; t < 6; t++) {
-            S6 c = ld6(L.cdof + 6 * (da + t));
-            vreal qd = ST(qvel, da + t);
-            acc = acc + mcross(vel0, c) * qd;
+    int cv = L.T2, ca = L.T2 + 6 * m.nbody, cf = L.Jaref;
+    VNL_SERIAL {
+      st6(cv, S6{v3(0, 0, 0), v3(0, 0, 0)});
+      st6(ca, S6{v3(0, 0, 0), v3(-m.gx, -m.gy, -m.gz)});
+      for (int b = 1; b < m.nbody; b++) {
+        int p = m.body_parent[b];
+        S6 vel = ld6(cv + 6 * p), acc = ld6(ca + 6 * p);
+        int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+        for (int k = 0; k < jn; k++) {
+          int j = ja + k, da = m.jnt_dofadr[j];
+          if (m.jnt_type[j] == VNL_JNT_FREE) {
+            for (int t = 0; t < 3; t++) vel = vel + ld6(L.cdof + 6 * (da + t)) * s[L.qvel + da + t];
+            S6 vel0 = vel;
+            for (int t = 3; t < 6; t++) {
+              S6 c = ld6(L.cdof + 6 * (da + t));
+              vreal qd = s[L.qvel + da + t];
+              acc = acc + mcross(vel0, c) * qd;
+              vel = vel + c * qd;
+            }
+          } else {
+            S6 c = ld6(L.cdof + 6 * da);
+            vreal qd = s[L.qvel + da];
+            acc = acc + mcross(vel, c) * qd;
             vel = vel + c * qd;
           }
-        } else {
-          S6 c = ld6(L.cdof + 6 * da);
-          vreal qd = ST(qvel, da);
-          acc = acc + mcross(vel, c) * qd;
-          vel = vel + c * qd;
         }
+        st6(cv + 6 * b, vel), st6(ca + 6 * b, acc);
       }
-      st6(cv + 6 * b, vel), st6(ca + 6 * b, acc);
-      S6 f = inert_mul(L.cinert + 10 * b, acc) + mcross_force(vel, inert_mul(L.cinert + 10 * b, vel));
-      st6(cf + 6 * b, f);
     }
-    for (int b = m.nbody - 1; b > 1; b--) {
-      int p = m.body_parent[b];
-      if (p > 0)
-        for (int k = 0; k < 6; k++) W(cf + 6 * p + k) += W(cf + 6 * b + k);
+    VNL_SYNC();
+    VNL_FOR(b, m.nbody) {
+      if (b == 0) {
+        st6(cf, S6{v3(0, 0, 0), v3(0, 0, 0)});
+        continue;
+      }
+      S6 vel = ld6(cv + 6 * b);
+      st6(cf + 6 * b, inert_mul(L.T1 + 10 * b, ld6(ca + 6 * b)) + mcross_force(vel, inert_mul(L.T1 + 10 * b, vel)));
     }
-    for (int d = 0; d < m.nv; d++) W(L.bias + d) = dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
+    VNL_SYNC();
+    tree_accumulate(cf, 6);
+    VNL_FOR(d, m.nv) s[L.bias + d] = dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
+    VNL_SYNC();
   }
 
   // passive + actuation + qfrc_smooth + qacc_smooth
   VNL_HD void smooth_forces() const {
-    for (int d = 0; d < m.nv; d++) {
-      W(L.smooth + d) = -m.dof_damping[d] * ST(qvel, d) - W(L.bias + d);
-      ST(qfrc_actuator, d) = vreal(0.);
+    VNL_FOR(d, m.nv) {
+      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - s[L.bias + d];
+      s[L.qfrc_act + d] = vreal(0.);
     }
-    for (int j = 0; j < m.njnt; j++) {
-      if (m.jnt_type[j] != VNL_JNT_HINGE) continue;
-      vreal k = m.jnt_stiffness[j];
-      if (k != vreal(0.)) W(L.smooth + m.jnt_dofadr[j]) -= k * (ST(qpos, m.jnt_qposadr[j]) - m.jnt_springref[j]);
-    }
-    for (int i = 0; i < m.nu; i++) {
-      vreal ctrl = W(L.ctrl + i), a = ctrl;
-      vreal tau = m.act_tau[i];
-      if (tau >= vreal(0.)) {
-        a = ST(act, i);
-        W(L.actdot + i) = (ctrl - a) / fmax(tau, VNL_MINVAL);
+    VNL_SYNC();
+    VNL_FOR(j, m.njnt) {
+      if (m.jnt_type[j] == VNL_JNT_HINGE) {
+        vreal k = m.jnt_stiffness[j];
+        if (k != vreal(0.)) s[L.smooth + m.jnt_dofadr[j]] -= k * (s[L.qpos + m.jnt_qposadr[j]] - m.jnt_springref[j]);
       }
-      ST(qfrc_actuator, m.act_dof[i]) += m.act_gear[i] * m.act_gain[i] * a;
     }
-    for (int d = 0; d < m.nv; d++) {
-      vreal s = W(L.smooth + d) + ST(qfrc_actuator, d);
-      W(L.smooth + d) = s;
-      W(L.qacc_smooth + d) = s;
+    VNL_SERIAL {  // several actuators may drive one dof: keep the accumulation ordered
+      for (int i = 0; i < m.nu; i++) {
+        vreal ctrl = s[L.ctrl + i], a = ctrl;
+        vreal tau = m.act_tau[i];
+        if (tau >= vreal(0.)) {
+          a = s[L.act + i];
+          s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
+        }
+        s[L.qfrc_act + m.act_dof[i]] += m.act_gear[i] * m.act_gain[i] * a;
+      }
     }
+    VNL_SYNC();
+    VNL_FOR(d, m.nv) {
+      vreal v = s[L.smooth + d] + s[L.qfrc_act + d];
+      s[L.smooth + d] = v;
+      s[L.qacc_smooth + d] = v;
+    }
+    VNL_SYNC();
     solve_inplace(L.qacc_smooth);
   }
 
@@ -370,34 +507,32 @@ struct EnvLane {
     if (x > vreal(1.)) imp = dmax;
   }
 
-  // collision (plane vs sphere / capsule / ellipsoid) + constraint rows.
-  // Rows that MJX would mask out (pos >= 0) get D = 0: they add nothing to cost,
-  // force or gradient.  Needs cvel (bodyB) from bias_forces for aref.
+  // collision (plane vs sphere / capsule / ellipsoid) + constraint rows, one lane per limit row /
+  // per geom.  Rows that MJX would mask out (pos >= 0) get D = 0: they add nothing to cost, force
+  // or gradient.  Needs cvel (T2) from bias_forces for aref.
   VNL_HD void make_constraint() const {
     V3 O = ref_point();
     V3 n = v3(m.pnx, m.pny, m.pnz), pp = v3(m.ppx, m.ppy, m.ppz);
-    for (int r = 0; r < m.nlimit; r++) {
-      vreal q = ST(qpos, m.lim_qadr[r]);
+    VNL_FOR(r, m.nlimit) {
+      vreal q = s[L.qpos + m.lim_qadr[r]];
       vreal dlo = q - m.lim_lo[r], dhi = m.lim_hi[r] - q;
       vreal pos = fmin(dlo, dhi) - m.lim_margin[r];
-      vreal sign = dlo < dhi ? vreal(1.) : -vreal(1.);
+      vreal sign = dlo < dhi ? vreal(1.) : vreal(-1.);
       vreal k, b, imp;
       kbimp(m.lim_solref + 2 * r, m.lim_solimp + 5 * r, m.dt, pos, k, b, imp);
       vreal R = fmax(m.lim_invweight[r] * (vreal(1.) - imp) / imp, VNL_MINVAL);
-      bool present = pos < vreal(0.);
-      W(L.lim_sign + r) = sign;
-      W(L.efc_D + r) = present ? vreal(1.) / R : vreal(0.);
-      W(L.efc_aref + r) = -b * (sign * ST(qvel, m.lim_dof[r])) - k * imp * pos;
+      s[L.lim_sign + r] = sign;
+      s[L.efc_D + r] = pos < vreal(0.) ? vreal(1.) / R : vreal(0.);
+      s[L.Jaref + r] = b * (sign * s[L.qvel + m.lim_dof[r]]) + k * imp * pos;  // -aref
     }
-    for (int g = 0; g < m.ncg; g++) {
+    VNL_FOR(g, m.ncg) {
       int bd = m.cg_body[g], c0 = m.cg_conadr[g], type = m.cg_type[g];
-      V3 bpos = V3{ST(xpos, 3 * bd), ST(xpos, 3 * bd + 1), ST(xpos, 3 * bd + 2)};
-      Q4 bq = Q4{ST(xquat, 4 * bd), ST(xquat, 4 * bd + 1), ST(xquat, 4 * bd + 2), ST(xquat, 4 * bd + 3)};
-      V3 gpos = bpos + qrot(t3(m.cg_pos, g), bq);
+      Q4 bq = ld4(L.xquat + 4 * bd);
+      V3 gpos = ld3(L.xpos + 3 * bd) + qrot(t3(m.cg_pos, g), bq);
       M3 R = qmat(qmul(bq, t4(m.cg_quat, g)));
       V3 size = t3(m.cg_size, g);
-      vreal dist[2];
-      V3 cpos[2], t1 = v3(m.t1x, m.t1y, m.t1z);
+      vreal dist0 = vreal(0.), dist1 = vreal(0.);
+      V3 cpos0 = v3(0, 0, 0), cpos1 = v3(0, 0, 0), t1 = v3(m.t1x, m.t1y, m.t1z);
       int nc = 1;
       if (type == VNL_GEOM_CAPSULE) {
         nc = 2;
@@ -405,21 +540,17 @@ struct EnvLane {
         V3 bv = axis - n * dot(n, axis);
         vreal bn = sqrt(dot(bv, bv));
         if (bn < vreal(0.5)) {
-          bv = (-vreal(0.5) < n.y && n.y < vreal(0.5)) ? v3(vreal(0.), vreal(1.), vreal(0.)) : v3(vreal(0.), vreal(0.), vreal(1.));
+          bv = (vreal(-0.5) < n.y && n.y < vreal(0.5)) ? v3(vreal(0.), vreal(1.), vreal(0.)) : v3(vreal(0.), vreal(0.), vreal(1.));
         } else {
           bv = bv * (vreal(1.) / bn);
         }
         t1 = bv;
-        for (int s = 0; s < 2; s++) {
-          V3 c = gpos + axis * (s == 0 ? size.y : -size.y);
-          vreal d = dot(c - pp, n) - size.x;
-          dist[s] = d;
-          cpos[s] = c - n * (size.x + vreal(0.5) * d);
-        }
+        V3 ca = gpos + axis * size.y, cb = gpos - axis * size.y;
+        dist0 = dot(ca - pp, n) - size.x, dist1 = dot(cb - pp, n) - size.x;
+        cpos0 = ca - n * (size.x + vreal(0.5) * dist0), cpos1 = cb - n * (size.x + vreal(0.5) * dist1);
       } else if (type == VNL_GEOM_SPHERE) {
-        vreal d = dot(gpos - pp, n) - size.x;
-        dist[0] = d;
-        cpos[0] = gpos - n * (size.x + vreal(0.5) * d);
+        dist0 = dot(gpos - pp, n) - size.x;
+        cpos0 = gpos - n * (size.x + vreal(0.5) * dist0);
       } else {
         V3 ln = V3{(R.a[0] * n.x + R.a[3] * n.y + R.a[6] * n.z) * size.x, (R.a[1] * n.x + R.a[4] * n.y + R.a[7] * n.z) * size.y,
                    (R.a[2] * n.x + R.a[5] * n.y + R.a[8] * n.z) * size.z};
@@ -427,157 +558,163 @@ struct EnvLane {
         vreal inv = nn > vreal(0.) ? vreal(1.) / nn : vreal(1.);
         V3 sup = V3{-ln.x * inv * size.x, -ln.y * inv * size.y, -ln.z * inv * size.z};
         V3 pos = gpos + mmul(R, sup);
-        vreal d = dot(n, pos - pp);
-        dist[0] = d;
-        cpos[0] = pos - n * (d * vreal(0.5));
+        dist0 = dot(n, pos - pp);
+        cpos0 = pos - n * (dist0 * vreal(0.5));
       }
       V3 t2 = cross(n, t1);
       vreal mu = m.cg_mu[g], margin = m.cg_margin[g], invw = m.cg_invweight[g];
-      S6 vel = ld6(L.bodyB + 6 * bd);
-      for (int s = 0; s < nc; s++) {
-        int c = c0 + s, r0 = m.nlimit + 4 * c;
-        vreal d = dist[s] - margin;
-        bool present = d < vreal(0.);
-        W(L.con_dist + c) = dist[s];
-        V3 rel = cpos[s] - O;
+      S6 vel = ld6(L.T2 + 6 * bd);
+      for (int q = 0; q < nc; q++) {
+        int c = c0 + q, r0 = m.nlimit + 4 * c;
+        vreal dist = q == 0 ? dist0 : dist1;
+        V3 rel = (q == 0 ? cpos0 : cpos1) - O;
+        vreal d = dist - margin;
+        s[L.con_dist + c] = dist;
         st3(L.con_r + 3 * c, rel);
         st3(L.con_t1 + 3 * c, t1);
-        vreal D = vreal(0.);
-        vreal ar[4] = {vreal(0.), vreal(0.), vreal(0.), vreal(0.)};
-        if (VNL_WAVE_ANY(present)) {
-          vreal k, b, imp;
-          kbimp(m.cg_solref + 2 * g, m.cg_solimp + 5 * g, m.dt, d, k, b, imp);
-          vreal Rr = fmax(invw * (vreal(1.) - imp) / imp, VNL_MINVAL);
-          D = present ? vreal(1.) / Rr : vreal(0.);
-          V3 pv = vel.l + cross(vel.a, rel);
-          vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
-          vreal kp = k * imp * d;
-          ar[0] = -b * (jn + j1) - kp, ar[1] = -b * (jn - j1) - kp;
-          ar[2] = -b * (jn + j2) - kp, ar[3] = -b * (jn - j2) - kp;
-        }
-        for (int q = 0; q < 4; q++) W(L.efc_D + r0 + q) = D, W(L.efc_aref + r0 + q) = ar[q];
+        vreal k, b, imp;
+        kbimp(m.cg_solref + 2 * g, m.cg_solimp + 5 * g, m.dt, d, k, b, imp);
+        vreal Rr = fmax(invw * (vreal(1.) - imp) / imp, VNL_MINVAL);
+        vreal D = d < vreal(0.) ? vreal(1.) / Rr : vreal(0.);
+        V3 pv = vel.l + cross(vel.a, rel);
+        vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
+        vreal kp = k * imp * d;
+        s[L.efc_D + r0] = D, s[L.efc_D + r0 + 1] = D, s[L.efc_D + r0 + 2] = D, s[L.efc_D + r0 + 3] = D;
+        s[L.Jaref + r0] = b * (jn + j1) + kp, s[L.Jaref + r0 + 1] = b * (jn - j1) + kp;  // -aref
+        s[L.Jaref + r0 + 2] = b * (jn + j2) + kp, s[L.Jaref + r0 + 3] = b * (jn - j2) + kp;
       }
     }
-  }
-
-  // body twists V[b] = sum_{d in path(b)} cdof[d] * vec[d]   -> bodyC[0 .. 6 nbody)
-  VNL_HD void body_twists(int vec) const {
-    int V = L.bodyC;
-    st6(V, S6{v3(0, 0, 0), v3(0, 0, 0)});
-    for (int b = 1; b < m.nbody; b++) {
-      S6 v = ld6(V + 6 * m.body_parent[b]);
-      int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
-      for (int k = 0; k < jn; k++) {
-        int j = ja + k, da = m.jnt_dofadr[j];
-        int nd = m.jnt_type[j] == VNL_JNT_FREE ? 6 : 1;
-        for (int t = 0; t < nd; t++) v = v + ld6(L.cdof + 6 * (da + t)) * W(vec + da + t);
-      }
-      st6(V + 6 * b, v);
+    VNL_SYNC();
+    VNL_SERIAL {  // list of contacts with D != 0 (typically a handful of the 59)
+      unsigned char* act = (unsigned char*)(s + L.act_list);
+      int na = 0;
+      for (int c = 0; c < m.ncon; c++)
+        if (s[L.efc_D + m.nlimit + 4 * c] != vreal(0.)) act[na++] = (unsigned char)c;
+      ((int*)(s + L.act_list))[(m.ncon + 3) / 4] = na;
     }
+    VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
+    VNL_SYNC();
   }
 
-  // out[r] = (J vec)[r] - sub[r]*use_sub   using the twists left by body_twists(vec)
-  VNL_HD void jac_mul(int vec, int out, bool subtract_aref) const {
+  // Tree prefix by pointer jumping: on entry buf0[6b+k] holds each body's own contribution; on exit
+  // the returned buffer holds the sum over the body's whole ancestor path.  jump_r[b] = 2^r-th
+  // ancestor (0 = none), log2(depth) rounds, ping-pong between buf0 and buf1.
+  VNL_HD int tree_prefix(int buf0, int buf1) const {
+    int src = buf0, dst = buf1;
+    for (int r = 0; r < m.jump_rounds; r++) {
+      const unsigned char* jr = m.jump + r * m.nbody;
+      VNL_FOR(i, 6 * m.nbody) {
+        int b = i / 6, j = jr[b];
+        vreal v = s[src + i];
+        if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
+        s[dst + i] = v;
+      }
+      VNL_SYNC();
+      int t = src;
+      src = dst, dst = t;
+    }
+    return src;
+  }
+
+  // body twists V[b] = sum_{d in path(b)} cdof[d] * vec[d]; returns the LDS offset of V (inside T2)
+  VNL_HD int body_twists(int vec) const {
+    int A = L.T2, Bf = L.T2 + 6 * m.nbody;
+    VNL_FOR(i, 6 * m.nbody) {
+      int b = i / 6, k = i - 6 * b;
+      int da = dofadr_of(b), nd = dofnum_of(b);
+      vreal v = vreal(0.);
+      for (int t = 0; t < nd; t++) v += s[L.cdof + 6 * (da + t) + k] * s[vec + da + t];
+      s[A + i] = v;
+    }
+    VNL_SYNC();
+    return tree_prefix(A, Bf);
+  }
+
+  // out[r] = (J vec)[r]  (accumulate: out[r] += ...), using the twists left by body_twists(vec)
+  VNL_HD void jac_mul(int V, int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    for (int r = 0; r < m.nlimit; r++) {
-      vreal v = W(L.lim_sign + r) * W(vec + m.lim_dof[r]);
-      if (subtract_aref) v -= W(L.efc_aref + r);
-      W(out + r) = v;
+    VNL_FOR(r, m.nlimit) {
+      vreal v = s[L.lim_sign + r] * s[vec + m.lim_dof[r]];
+      s[out + r] = accumulate ? s[out + r] + v : v;
     }
-    for (int g = 0; g < m.ncg; g++) {
-      int bd = m.cg_body[g], c0 = m.cg_conadr[g], nc = m.cg_ncon[g];
+    const unsigned char* act = (const unsigned char*)(s + L.act_list);
+    int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
+    VNL_FOR(j, na) {
+      int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
       vreal mu = m.cg_mu[g];
-      S6 vel = ld6(L.bodyC + 6 * bd);
-      for (int s = 0; s < nc; s++) {
-        int c = c0 + s, r0 = m.nlimit + 4 * c;
-        vreal D = W(L.efc_D + r0);
-        vreal o0 = vreal(0.), o1 = vreal(0.), o2 = vreal(0.), o3 = vreal(0.);
-        if (VNL_WAVE_ANY(D != vreal(0.))) {
-          V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
-          V3 pv = vel.l + cross(vel.a, rel);
-          vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
-          o0 = jn + j1, o1 = jn - j1, o2 = jn + j2, o3 = jn - j2;
-          if (subtract_aref)
-            o0 -= W(L.efc_aref + r0), o1 -= W(L.efc_aref + r0 + 1), o2 -= W(L.efc_aref + r0 + 2),
-                o3 -= W(L.efc_aref + r0 + 3);
-        }
-        W(out + r0) = o0, W(out + r0 + 1) = o1, W(out + r0 + 2) = o2, W(out + r0 + 3) = o3;
-      }
+      S6 vel = ld6(V + 6 * con_body(c));
+      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
+      V3 pv = vel.l + cross(vel.a, rel);
+      vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
+      vreal o0 = jn + j1, o1 = jn - j1, o2 = jn + j2, o3 = jn - j2;
+      if (accumulate) o0 += s[out + r0], o1 += s[out + r0 + 1], o2 += s[out + r0 + 2], o3 += s[out + r0 + 3];
+      s[out + r0] = o0, s[out + r0 + 1] = o1, s[out + r0 + 2] = o2, s[out + r0 + 3] = o3;
     }
-  }
-
-  // out = M vec, matrix-free, using the twists left by body_twists(vec)
-  VNL_HD void mass_mul(int vec, int out) const {
-    int V = L.bodyC, F = L.bodyC + 6 * m.nbody;
-    for (int b = 1; b < m.nbody; b++) st6(F + 6 * b, inert_mul(L.cinert + 10 * b, ld6(V + 6 * b)));
-    for (int b = m.nbody - 1; b > 1; b--) {
-      int p = m.body_parent[b];
-      if (p > 0)
-        for (int k = 0; k < 6; k++) W(F + 6 * p + k) += W(F + 6 * b + k);
-    }
-    for (int d = 0; d < m.nv; d++)
-      W(out + d) = dot(ld6(L.cdof + 6 * d), ld6(F + 6 * m.dof_body[d])) + m.dof_armature[d] * W(vec + d);
+    VNL_SYNC();
   }
 
   // 0.5 * sum_r D Jaref^2 [Jaref<0]
   VNL_HD vreal constraint_cost(int jaref) const {
     vreal c = vreal(0.);
-    for (int r = 0; r < m.nefc; r++) {
-      vreal D = W(L.efc_D + r);
-      if (!VNL_WAVE_ANY(D != vreal(0.))) continue;
-      vreal x = W(jaref + r);
-      c += x < vreal(0.) ? D * x * x : vreal(0.);
+    VNL_FOR(r, m.nefc) {
+      vreal x = s[jaref + r];
+      c += x < vreal(0.) ? s[L.efc_D + r] * x * x : vreal(0.);
     }
-    return vreal(0.5) * c;
+    return vreal(0.5) * vnl_wave_sum(c);
   }
 
-  // qfrc_constraint = J' f with f = -D Jaref [Jaref<0]; returns the constraint cost
+  // qfrc_constraint = J' f with f = -D Jaref [Jaref<0]; returns the constraint cost.
+  // Per-contact wrenches (about O) are formed in parallel; then each dof sums the wrenches of the
+  // contacts in its body's subtree (bodies are numbered depth-first, so the subtree is a contiguous
+  // body range) and projects onto its own cdof.  Only contacts with D != 0 are listed (active list
+  // built by make_constraint).
   VNL_HD vreal constraint_force() const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    int Wb = L.bodyC + 6 * m.nbody;
+    int Wc = L.T1;
+    const unsigned char* act = (const unsigned char*)(s + L.act_list);
+    int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     vreal cost = vreal(0.);
-    for (int k = 6; k < 6 * m.nbody; k++) W(Wb + k) = vreal(0.);
-    for (int d = 0; d < m.nv; d++) W(L.qfrc_c + d) = vreal(0.);
-    for (int r = 0; r < m.nlimit; r++) {
-      vreal D = W(L.efc_D + r);
-      if (!VNL_WAVE_ANY(D != vreal(0.))) continue;
-      vreal x = W(L.Jaref + r);
-      vreal f = x < vreal(0.) ? -D * x : vreal(0.);
-      cost += x < vreal(0.) ? D * x * x : vreal(0.);
-      W(L.qfrc_c + m.lim_dof[r]) += W(L.lim_sign + r) * f;
+    VNL_FOR(r, m.nlimit) {
+      vreal x = s[L.Jaref + r];
+      cost += x < vreal(0.) ? s[L.efc_D + r] * x * x : vreal(0.);
     }
-    for (int g = 0; g < m.ncg; g++) {
-      int bd = m.cg_body[g], c0 = m.cg_conadr[g], nc = m.cg_ncon[g];
-      vreal mu = m.cg_mu[g];
-      for (int s = 0; s < nc; s++) {
-        int c = c0 + s, r0 = m.nlimit + 4 * c;
-        vreal D = W(L.efc_D + r0);
-        if (!VNL_WAVE_ANY(D != vreal(0.))) continue;
-        vreal f[4];
-        for (int q = 0; q < 4; q++) {
-          vreal x = W(L.Jaref + r0 + q);
-          f[q] = x < vreal(0.) ? -D * x : vreal(0.);
-          cost += x < vreal(0.) ? D * x * x : vreal(0.);
-        }
-        V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
-        V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
-        S6 w = S6{cross(rel, Fw), Fw};
-        st6(Wb + 6 * bd, ld6(Wb + 6 * bd) + w);
+    VNL_FOR(j, na) {
+      int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
+      vreal D = s[L.efc_D + r0];
+      vreal mu = m.cg_mu[g], f[4];
+      for (int q = 0; q < 4; q++) {
+        vreal x = s[L.Jaref + r0 + q];
+        f[q] = x < vreal(0.) ? -D * x : vreal(0.);
+        cost += x < vreal(0.) ? D * x * x : vreal(0.);
       }
+      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
+      V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
+      st6(Wc + 6 * j, S6{cross(rel, Fw), Fw});
     }
-    for (int b = m.nbody - 1; b > 1; b--) {
-      int p = m.body_parent[b];
-      if (p > 0)
-        for (int k = 0; k < 6; k++) W(Wb + 6 * p + k) += W(Wb + 6 * b + k);
+    VNL_SYNC();
+    VNL_FOR(d, m.nv) {
+      int b0 = m.dof_body[d], b1 = b0 + m.body_nsub[b0];
+      S6 w = S6{v3(0, 0, 0), v3(0, 0, 0)};
+      for (int j = 0; j < na; j++) {
+        int cb = con_body(act[j]);
+        if (cb >= b0 && cb <= b1) w = w + ld6(Wc + 6 * j);
+      }
+      vreal q = dot(ld6(L.cdof + 6 * d), w);
+      int r = m.dof_limrow[d];
+      if (r >= 0) {
+        vreal x = s[L.Jaref + r];
+        q += x < vreal(0.) ? s[L.lim_sign + r] * (-s[L.efc_D + r] * x) : vreal(0.);
+      }
+      s[L.qfrc_c + d] = q;
     }
-    for (int d = 0; d < m.nv; d++) W(L.qfrc_c + d) += dot(ld6(L.cdof + 6 * d), ld6(Wb + 6 * m.dof_body[d]));
-    return vreal(0.5) * cost;
+    VNL_SYNC();
+    return vreal(0.5) * vnl_wave_sum(cost);
   }
 
   VNL_HD vreal vdot(int a, int b) const {
-    vreal s = vreal(0.);
-    for (int d = 0; d < m.nv; d++) s += W(a + d) * W(b + d);
-    return s;
+    vreal p = vreal(0.);
+    VNL_FOR(d, m.nv) p += s[a + d] * s[b + d];
+    return vnl_wave_sum(p);
   }
 
   // one pass over the rows for up to 3 step lengths: quad totals -> (cost, d0, d1)
@@ -587,11 +724,11 @@ struct EnvLane {
   template <int N>
   VNL_HD void ls_eval(const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
     vreal q0[N], q1[N], q2[N];
-    for (int i = 0; i < N; i++) q0[i] = qg0, q1[i] = qg1, q2[i] = qg2;
-    for (int r = 0; r < m.nefc; r++) {
-      vreal D = W(L.efc_D + r);
-      if (!VNL_WAVE_ANY(D != vreal(0.))) continue;
-      vreal ja = W(L.Jaref + r), jv = W(L.jv + r);
+    for (int i = 0; i < N; i++) q0[i] = vreal(0.), q1[i] = vreal(0.), q2[i] = vreal(0.);
+    VNL_FOR(r, m.nefc) {
+      vreal D = s[L.efc_D + r];
+      if (D == vreal(0.)) continue;
+      vreal ja = s[L.Jaref + r], jv = s[L.jv + r];
       vreal a0 = vreal(0.5) * ja * ja * D, a1 = jv * ja * D, a2 = vreal(0.5) * jv * jv * D;
       for (int i = 0; i < N; i++) {
         bool act = ja + alpha[i] * jv < vreal(0.);
@@ -599,66 +736,75 @@ struct EnvLane {
       }
     }
     for (int i = 0; i < N; i++) {
+      vreal t0 = qg0 + vnl_wave_sum(q0[i]), t1 = qg1 + vnl_wave_sum(q1[i]), t2 = qg2 + vnl_wave_sum(q2[i]);
       vreal a = alpha[i];
       out[i].alpha = a;
-      out[i].cost = a * a * q2[i] + a * q1[i] + q0[i];
-      out[i].d0 = vreal(2.) * a * q2[i] + q1[i];
-      out[i].d1 = vreal(2.) * q2[i] + (q2[i] == vreal(0.) ? VNL_MINVAL : vreal(0.));
+      out[i].cost = a * a * t2 + a * t1 + t0;
+      out[i].d0 = vreal(2.) * a * t2 + t1;
+      out[i].d1 = vreal(2.) * t2 + (t2 == vreal(0.) ? VNL_MINVAL : vreal(0.));
     }
   }
 
-  // solver.solve (CG) -- per-lane freezing reproduces vmap-of-while semantics
+  // solver.solve (CG).  One env per wave: the while loops run with this env's own trip counts.
   VNL_HD void solve() const {
     const int nv = m.nv, ne = m.nefc;
-    // --- warm start selection: cost at qacc_warmstart vs qacc_smooth
-    for (int d = 0; d < nv; d++) W(L.qacc + d) = ST(warm, d);
-    body_twists(L.qacc);
-    jac_mul(L.qacc, L.jv, true);  // Jaref(warm) in jv
-    mass_mul(L.qacc, L.mv);       // Ma(warm) in mv
-    vreal gw = vreal(0.);
-    for (int d = 0; d < nv; d++) gw += (W(L.mv + d) - W(L.smooth + d)) * (W(L.qacc + d) - W(L.qacc_smooth + d));
-    vreal cost_w = constraint_cost(L.jv) + vreal(0.5) * gw;
-    body_twists(L.qacc_smooth);
-    jac_mul(L.qacc_smooth, L.Jaref, true);
+    int V;
+    // --- warm start selection: cost at qacc_warmstart vs qacc_smooth.
+    // On entry: Jaref holds -aref (make_constraint), mv holds M*warm, qacc holds warm (forward()).
+    V = body_twists(L.qacc_smooth);
+    jac_mul(V, L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
     vreal cost_s = constraint_cost(L.Jaref);  // gauss term vanishes: M qacc_smooth = qfrc_smooth
+    VNL_FOR(d, nv) s[L.tmp + d] = s[L.qacc + d] - s[L.qacc_smooth + d];
+    VNL_SYNC();
+    V = body_twists(L.tmp);
+    jac_mul(V, L.tmp, L.jv, false);  // J (warm - smooth)
+    VNL_FOR(r, ne) s[L.jv + r] += s[L.Jaref + r];  // Jaref(warm)
+    vreal gw = vreal(0.);
+    VNL_FOR(d, nv) gw += (s[L.mv + d] - s[L.smooth + d]) * s[L.tmp + d];
+    gw = vnl_wave_sum(gw);
+    VNL_SYNC();
+    vreal cost_w = constraint_cost(L.jv) + vreal(0.5) * gw;
     bool use_warm = cost_w < cost_s;
-    for (int d = 0; d < nv; d++) {
-      W(L.qacc + d) = use_warm ? W(L.qacc + d) : W(L.qacc_smooth + d);
-      W(L.Ma + d) = use_warm ? W(L.mv + d) : W(L.smooth + d);
+    VNL_FOR(d, nv) {
+      s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
+      s[L.Ma + d] = use_warm ? s[L.mv + d] : s[L.smooth + d];
     }
-    if (VNL_WAVE_ANY(use_warm))
-      for (int r = 0; r < ne; r++) W(L.Jaref + r) = use_warm ? W(L.jv + r) : W(L.Jaref + r);
+    if (use_warm) {
+      VNL_FOR(r, ne) s[L.Jaref + r] = s[L.jv + r];
+    }
+    VNL_SYNC();
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
     vreal cost = constraint_force() + gauss;
     vreal prev_cost = INFINITY;
-    for (int d = 0; d < nv; d++) {
-      vreal g = W(L.Ma + d) - W(L.smooth + d) - W(L.qfrc_c + d);
-      W(L.grad + d) = g, W(L.Mgrad + d) = g;
+    VNL_FOR(d, nv) {
+      vreal g = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
+      s[L.grad + d] = g, s[L.Mgrad + d] = g;
     }
+    VNL_SYNC();
     solve_inplace(L.Mgrad);
-    for (int d = 0; d < nv; d++) W(L.search + d) = -W(L.Mgrad + d);
+    VNL_FOR(d, nv) {
+      s[L.search + d] = -s[L.Mgrad + d];
+      s[L.mv + d] = -s[L.grad + d];  // M search
+    }
+    VNL_SYNC();
     VNL_PROF(6);
 
-    bool done = false;
     for (int it = 0; it < m.iterations; it++) {
       vreal improvement = (prev_cost - cost) / m.scale;
       vreal gradient = sqrt(vdot(L.grad, L.grad)) / m.scale;
-      done = done || (improvement < m.tolerance) || (gradient < m.tolerance);
-      if (!VNL_WAVE_ANY(!done)) break;
-      const bool run = !done;
+      if (improvement < m.tolerance || gradient < m.tolerance) break;
       // ---- line search
       vreal smag = sqrt(vdot(L.search, L.search)) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
-      body_twists(L.search);
-      jac_mul(L.search, L.jv, false);
-      mass_mul(L.search, L.mv);
+      V = body_twists(L.search);
+      jac_mul(V, L.search, L.jv, false);
       vreal qg1 = vreal(0.), qg2 = vreal(0.);
-      for (int d = 0; d < nv; d++) {
-        vreal s = W(L.search + d);
-        qg1 += s * W(L.Ma + d) - s * W(L.smooth + d);
-        qg2 += s * W(L.mv + d);
+      VNL_FOR(d, nv) {
+        vreal sd = s[L.search + d];
+        qg1 += sd * s[L.Ma + d] - sd * s[L.smooth + d];
+        qg2 += sd * s[L.mv + d];
       }
-      qg2 *= vreal(0.5);
+      qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(7);
       LsPoint p0, lo, hi;
       vreal a1[1] = {vreal(0.)};
@@ -670,68 +816,78 @@ struct EnvLane {
       } else {
         hi = lo, lo = p0;
       }
-      bool ls_done = !run, swap = true;
+      bool swap = true;
       for (int li = 0; li < m.ls_iterations; li++) {
-        ls_done = ls_done || !swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol);
-        if (!VNL_WAVE_ANY(!ls_done)) break;
+        if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
         vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
         LsPoint p[3];
         ls_eval<3>(a3, gauss, qg1, qg2, p);
-        LsPoint nlo = lo, nhi = hi;
-        bool s1 = (nlo.d0 > vreal(0.)) || (nlo.d0 < p[0].d0);
-        if (s1) nlo = p[0];
-        bool s2 = (p[2].d0 < vreal(0.)) && (nlo.d0 < p[2].d0);
-        if (s2) nlo = p[2];
-        bool s3 = (nhi.d0 < vreal(0.)) || (nhi.d0 > p[1].d0);
-        if (s3) nhi = p[1];
-        bool s4 = (p[2].d0 > vreal(0.)) && (nhi.d0 > p[2].d0);
-        if (s4) nhi = p[2];
-        if (!ls_done) lo = nlo, hi = nhi, swap = s1 || s2 || s3 || s4;
+        bool s1 = (lo.d0 > vreal(0.)) || (lo.d0 < p[0].d0);
+        if (s1) lo = p[0];
+        bool s2 = (p[2].d0 < vreal(0.)) && (lo.d0 < p[2].d0);
+        if (s2) lo = p[2];
+        bool s3 = (hi.d0 < vreal(0.)) || (hi.d0 > p[1].d0);
+        if (s3) hi = p[1];
+        bool s4 = (p[2].d0 > vreal(0.)) && (hi.d0 > p[2].d0);
+        if (s4) hi = p[2];
+        swap = s1 || s2 || s3 || s4;
       }
-      bool improved = run && ((lo.cost < p0.cost) || (hi.cost < p0.cost));
+      bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
       vreal alpha = improved ? (lo.cost < hi.cost ? lo.alpha : hi.alpha) : vreal(0.);
-      for (int d = 0; d < nv; d++) {
-        W(L.qacc + d) += alpha * W(L.search + d);
-        W(L.Ma + d) += alpha * W(L.mv + d);
+      VNL_FOR(d, nv) {
+        s[L.qacc + d] += alpha * s[L.search + d];
+        s[L.Ma + d] += alpha * s[L.mv + d];
       }
-      for (int r = 0; r < ne; r++) W(L.Jaref + r) += alpha * W(L.jv + r);
+      VNL_FOR(r, ne) s[L.Jaref + r] += alpha * s[L.jv + r];
+      VNL_SYNC();
       VNL_PROF(8);
       // ---- constraint + gradient update
       vreal gp = vdot(L.grad, L.Mgrad);
       vreal g = vreal(0.);
-      for (int d = 0; d < nv; d++) g += (W(L.Ma + d) - W(L.smooth + d)) * (W(L.qacc + d) - W(L.qacc_smooth + d));
+      VNL_FOR(d, nv) g += (s[L.Ma + d] - s[L.smooth + d]) * (s[L.qacc + d] - s[L.qacc_smooth + d]);
+      g = vnl_wave_sum(g);
       vreal ncost = constraint_force() + vreal(0.5) * g;
-      if (run) prev_cost = cost, cost = ncost, gauss = vreal(0.5) * g;
+      prev_cost = cost, cost = ncost, gauss = vreal(0.5) * g;
       vreal d1 = vreal(0.);
-      for (int d = 0; d < nv; d++) {
-        vreal gn = W(L.Ma + d) - W(L.smooth + d) - W(L.qfrc_c + d);
-        d1 += gn * W(L.Mgrad + d);
-        W(L.grad + d) = gn, W(L.tmp + d) = gn;
+      VNL_FOR(d, nv) {
+        vreal gn = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
+        d1 += gn * s[L.Mgrad + d];
+        s[L.grad + d] = gn, s[L.tmp + d] = gn;
       }
+      d1 = vnl_wave_sum(d1);
+      VNL_SYNC();
       VNL_PROF(9);
       solve_inplace(L.tmp);
       VNL_PROF(10);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
-      for (int d = 0; d < nv; d++) {
-        vreal mg = W(L.tmp + d);
-        W(L.Mgrad + d) = mg;
-        if (run) W(L.search + d) = -mg + beta * W(L.search + d);
+      VNL_FOR(d, nv) {
+        vreal mg = s[L.tmp + d];
+        s[L.Mgrad + d] = mg;
+        s[L.search + d] = -mg + beta * s[L.search + d];
+        s[L.mv + d] = -s[L.grad + d] + beta * s[L.mv + d];
       }
+      VNL_SYNC();
     }
-    for (int d = 0; d < nv; d++) ST(warm, d) = W(L.qacc + d);
   }
 
-  // forward.forward
-  VNL_HD void forward() const {
+  // forward.forward.  `warm` = qacc_warmstart (HBM on the first substep, LDS qacc afterwards).
+  VNL_HD void forward(const vreal* warm) const {
+    VNL_FOR(d, m.nv) s[L.tmp + d] = warm[d];
+    VNL_SYNC();
+    VNL_FOR(d, m.nv) s[L.qacc + d] = s[L.tmp + d];
+    VNL_SYNC();
     kinematics();
     VNL_PROF(0);
-    crb_mass_matrix();
-    VNL_PROF(1);
-    factor(vreal(0.));
-    VNL_PROF(2);
+    body_inertias(true);
     bias_forces();
     VNL_PROF(3);
+    mass_matrix(vreal(0.));
+    VNL_PROF(1);
+    factor();
+    mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
+    invert_factor();
+    VNL_PROF(2);
     smooth_forces();
     VNL_PROF(4);
     make_constraint();
@@ -739,73 +895,48 @@ struct EnvLane {
     solve();
   }
 
-  // forward.euler + _advance
+  // forward.euler + _advance; leaves qacc (warm start) in L.qacc and the new state in L.qpos/qvel/act
   VNL_HD void euler() const {
     const int nv = m.nv;
-    for (int d = 0; d < nv; d++) W(L.tmp + d) = m.eulerdamp ? W(L.smooth + d) + W(L.qfrc_c + d) : W(L.qacc + d);
+    VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
+    VNL_SYNC();
     VNL_PROF(11);
     if (m.eulerdamp) {
-      factor(m.dt);
+      body_inertias(false);
+      mass_matrix(m.dt);
+      factor();
+      invert_factor();
       VNL_PROF(12);
       solve_inplace(L.tmp);
     }
-    for (int i = 0; i < m.nu; i++)
-      if (m.act_tau[i] >= vreal(0.)) ST(act, i) += W(L.actdot + i) * m.dt;
-    for (int d = 0; d < nv; d++) ST(qvel, d) += W(L.tmp + d) * m.dt;
-    for (int j = 0; j < m.njnt; j++) {
+    VNL_FOR(i, m.nu) {
+      if (m.act_tau[i] >= vreal(0.)) s[L.act + i] += s[L.actdot + i] * m.dt;
+    }
+    VNL_FOR(d, nv) s[L.qvel + d] += s[L.tmp + d] * m.dt;
+    VNL_SYNC();
+    VNL_FOR(j, m.njnt) {
       int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
       if (m.jnt_type[j] == VNL_JNT_FREE) {
-        for (int t = 0; t < 3; t++) ST(qpos, qa + t) += m.dt * ST(qvel, da + t);
-        V3 w = V3{ST(qvel, da + 3), ST(qvel, da + 4), ST(qvel, da + 5)};
+        for (int t = 0; t < 3; t++) s[L.qpos + qa + t] += m.dt * s[L.qvel + da + t];
+        V3 w = ld3(L.qvel + da + 3);
         vreal nrm = sqrt(dot(w, w));
         V3 ax = nrm > vreal(0.) ? w * (vreal(1.) / nrm) : w;
-        vreal ang = m.dt * nrm, s = sin(vreal(0.5) * ang), c = cos(vreal(0.5) * ang);
-        Q4 q = Q4{ST(qpos, qa + 3), ST(qpos, qa + 4), ST(qpos, qa + 5), ST(qpos, qa + 6)};
-        Q4 r = qmul(q, Q4{c, ax.x * s, ax.y * s, ax.z * s});
+        vreal ang = m.dt * nrm, sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
+        Q4 r = qmul(ld4(L.qpos + qa + 3), Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
         vreal n2 = sqrt(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
         vreal inv = n2 > vreal(0.) ? vreal(1.) / n2 : vreal(1.);
-        ST(qpos, qa + 3) = r.w * inv, ST(qpos, qa + 4) = r.x * inv, ST(qpos, qa + 5) = r.y * inv,
-                 ST(qpos, qa + 6) = r.z * inv;
+        s[L.qpos + qa + 3] = r.w * inv, s[L.qpos + qa + 4] = r.x * inv, s[L.qpos + qa + 5] = r.y * inv,
+                        s[L.qpos + qa + 6] = r.z * inv;
       } else {
-        ST(qpos, qa) += m.dt * ST(qvel, da);
+        s[L.qpos + qa] += m.dt * s[L.qvel + da];
       }
     }
+    VNL_SYNC();
     VNL_PROF(13);
   }
 
   // ------------------------------------------------------------------ env glue
   VNL_HD static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-  // rodent.py:241-264 (matrix 1-norm over the tracked bodies, L1 over joints)
-  VNL_HD vreal termination(int clip, int frame) const {
-    int f = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
-    const float* cj = ev.joints + ((size_t)clip * ev.T + f) * nj;
-    vreal ej = vreal(0.);
-    for (int i = 0; i < nj; i++) ej += fabs(cj[i] - ST(qpos, 7 + i));
-    const float* cb = ev.body_positions + ((size_t)clip * ev.T + f) * ev.nb * 3;
-    vreal cx = vreal(0.), cy = vreal(0.), cz = vreal(0.);
-    for (int k = 0; k < ev.nb; k++) {
-      int bd = ev.body_idxs[k];
-      cx += fabs(cb[3 * k] - ST(xpos, 3 * bd));
-      cy += fabs(cb[3 * k + 1] - ST(xpos, 3 * bd + 1));
-      cz += fabs(cb[3 * k + 2] - ST(xpos, 3 * bd + 2));
-    }
-    vreal eb = fmax(cx, fmax(cy, cz));
-    vreal err = vreal(0.5) * ev.body_err_mult * eb + vreal(0.5) * ej;
-    return vreal(1.) - err * ev.inv_term_threshold;
-  }
-
-  // rodent.py:318-344
-  VNL_HD void write_obs() const {
-    int k = 0;
-    for (int i = 0; i < m.nq; i++) ST(obs, k++) = nan0(ST(qpos, i));
-    for (int i = 0; i < m.nv; i++) ST(obs, k++) = nan0(ST(qvel, i));
-    for (int i = 0; i < m.nv; i++) ST(obs, k++) = nan0(ST(qfrc_actuator, i));
-    for (int j = 0; j < ev.nee; j++) {
-      int bd = ev.end_eff_idx[j];
-      for (int i = 0; i < 3; i++) ST(obs, k++) = nan0(ST(xpos, 3 * bd + i));
-    }
-  }
   // jp.nan_to_num
   VNL_HD static vreal nan0(vreal x) {
     if (x != x) return vreal(0.);
@@ -814,152 +945,223 @@ struct EnvLane {
     return x;
   }
 
-  // rodent.py:346-448; local frame = v @ xmat[1]
-  VNL_HD void write_traj(int clip, int frame) const {
-    int Lr = ev.ref_len, s = clampi(frame + 1, 0, ev.T - Lr), nj = m.nq - 7, k = 0;
-    M3 R = qmat(Q4{ST(xquat, 4), ST(xquat, 5), ST(xquat, 6), ST(xquat, 7)});
-    size_t fb = (size_t)clip * ev.T + s;
-    for (int t = 0; t < Lr; t++) {
-      const float* cb = ev.body_positions + (fb + t) * ev.nb * 3;
-      for (int a = 0; a < ev.napp; a++) {
-        int col = ev.app_ref_col[a];
-        for (int i = 0; i < 3; i++) ST(traj, k++) = cb[3 * col + i];
-      }
+  // rodent.py:241-264 (matrix 1-norm over the tracked bodies, L1 over joints); qpos / xpos given
+  // as pointers so that both the carried (global) and the fresh (LDS) state can be scored
+  VNL_HD vreal termination(int clip, int frame, const vreal* qpos, const vreal* xpos) const {
+    int f = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
+    const float* cj = ev.joints + ((size_t)clip * ev.T + f) * nj;
+    const float* cb = ev.body_positions + ((size_t)clip * ev.T + f) * ev.nb * 3;
+    vreal ej = vreal(0.), cx = vreal(0.), cy = vreal(0.), cz = vreal(0.);
+    VNL_FOR(i, nj) ej += fabs(vreal(cj[i]) - qpos[7 + i]);
+    VNL_FOR(k, ev.nb) {
+      int bd = ev.body_idxs[k];
+      cx += fabs(vreal(cb[3 * k]) - xpos[3 * bd]);
+      cy += fabs(vreal(cb[3 * k + 1]) - xpos[3 * bd + 1]);
+      cz += fabs(vreal(cb[3 * k + 2]) - xpos[3 * bd + 2]);
     }
-    int kg = k + Lr * ev.nb * 3;  // global block follows the local block
-    for (int t = 0; t < Lr; t++) {
-      const float* cb = ev.body_positions + (fb + t) * ev.nb * 3;
-      for (int b = 0; b < ev.nb; b++) {
-        int bd = ev.body_idxs[b];
-        V3 v = V3{cb[3 * b] - ST(xpos, 3 * bd), cb[3 * b + 1] - ST(xpos, 3 * bd + 1), cb[3 * b + 2] - ST(xpos, 3 * bd + 2)};
-        ST(traj, k++) = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
-        ST(traj, k++) = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
-        ST(traj, k++) = v.x * R.a[2] + v.y * R.a[5] + v.z * R.a[8];
-        ST(traj, kg++) = v.x, ST(traj, kg++) = v.y, ST(traj, kg++) = v.z;
-      }
-    }
-    k = kg;
-    for (int t = 0; t < Lr; t++) {
-      const float* cp = ev.position + (fb + t) * 3;
-      V3 v = V3{cp[0] - ST(qpos, 0), cp[1] - ST(qpos, 1), cp[2] - ST(qpos, 2)};
-      ST(traj, k++) = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
-      ST(traj, k++) = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
-      ST(traj, k++) = v.x * R.a[2] + v.y * R.a[5] + v.z * R.a[8];
-    }
-    for (int t = 0; t < Lr; t++) {
-      const float* cj = ev.joints + (fb + t) * nj;
-      for (int j = 0; j < ev.njc; j++) {
-        int col = ev.joint_cols[j];
-        ST(traj, k++) = cj[col] - ST(qpos, 7 + col);
-      }
-    }
+    ej = vnl_wave_sum(ej), cx = vnl_wave_sum(cx), cy = vnl_wave_sum(cy), cz = vnl_wave_sum(cz);
+    vreal eb = fmax(cx, fmax(cy, cz));
+    vreal err = vreal(0.5) * ev.body_err_mult * eb + vreal(0.5) * ej;
+    return vreal(1.) - err * ev.inv_term_threshold;
   }
 
-  VNL_HD bool any_nan() const {
+  // carried state: HBM -> LDS
+  VNL_HD void load_state() const {
+    const vreal* gq = st.qpos + (size_t)e * m.nq;
+    const vreal* gv = st.qvel + (size_t)e * m.nv;
+    const vreal* ga = st.act + (size_t)e * m.nu;
+    VNL_FOR(i, m.nq) s[L.qpos + i] = gq[i];
+    VNL_FOR(i, m.nv) s[L.qvel + i] = gv[i];
+    VNL_FOR(i, m.nu) s[L.act + i] = ga[i];
+    VNL_SYNC();
+  }
+
+  // new state + derived quantities: LDS -> HBM; returns true if anything is NaN
+  VNL_HD bool store_state() const {
+    vreal* gq = st.qpos + (size_t)e * m.nq;
+    vreal* gv = st.qvel + (size_t)e * m.nv;
+    vreal* ga = st.act + (size_t)e * m.nu;
+    vreal* gw = st.warm + (size_t)e * m.nv;
+    vreal* gf = st.qfrc_actuator + (size_t)e * m.nv;
+    vreal* gx = st.xpos + (size_t)e * 3 * m.nbody;
+    vreal* gxq = st.xquat + (size_t)e * 4 * m.nbody;
     bool bad = false;
-    for (int i = 0; i < m.nq; i++) bad |= ST(qpos, i) != ST(qpos, i);
-    for (int i = 0; i < m.nv; i++) {
-      vreal a = ST(qvel, i), b = ST(warm, i), c = ST(qfrc_actuator, i);
+    VNL_FOR(i, m.nq) {
+      vreal v = s[L.qpos + i];
+      gq[i] = v, bad |= v != v;
+    }
+    VNL_FOR(i, m.nv) {
+      vreal a = s[L.qvel + i], b = s[L.qacc + i], c = s[L.qfrc_act + i];
+      gv[i] = a, gw[i] = b, gf[i] = c;
       bad |= (a != a) | (b != b) | (c != c);
     }
-    for (int i = 0; i < m.nu; i++) bad |= ST(act, i) != ST(act, i);
-    for (int i = 0; i < 3 * m.nbody; i++) bad |= ST(xpos, i) != ST(xpos, i);
-    for (int i = 0; i < 3; i++) bad |= ST(com1, i) != ST(com1, i);
-    return bad;
+    VNL_FOR(i, m.nu) {
+      vreal v = s[L.act + i];
+      ga[i] = v, bad |= v != v;
+    }
+    VNL_FOR(i, 3 * m.nbody) {
+      vreal v = s[L.xpos + i];
+      gx[i] = v, bad |= v != v;
+    }
+    VNL_FOR(i, 4 * m.nbody) gxq[i] = s[L.xquat + i];
+    VNL_FOR(i, 3) {
+      vreal v = s[L.com + i];
+      st.com1[(size_t)e * 3 + i] = v, bad |= v != v;
+    }
+    return vnl_wave_any(bad);
+  }
+
+  // rodent.py:318-344
+  VNL_HD void write_obs() const {
+    vreal* o = st.obs + (size_t)e * ev.obs_size;
+    VNL_FOR(i, m.nq) o[i] = nan0(s[L.qpos + i]);
+    VNL_FOR(i, m.nv) o[m.nq + i] = nan0(s[L.qvel + i]);
+    VNL_FOR(i, m.nv) o[m.nq + m.nv + i] = nan0(s[L.qfrc_act + i]);
+    VNL_FOR(k, 3 * ev.nee) o[m.nq + 2 * m.nv + k] = nan0(s[L.xpos + 3 * ev.end_eff_idx[k / 3] + k % 3]);
+  }
+
+  // rodent.py:346-448; local frame = v @ xmat[1]
+  VNL_HD void write_traj(int clip, int frame) const {
+    int Lr = ev.ref_len, s0 = clampi(frame + 1, 0, ev.T - Lr), nj = m.nq - 7;
+    M3 R = qmat(ld4(L.xquat + 4));
+    size_t fb = (size_t)clip * ev.T + s0;
+    vreal* tr = st.traj + (size_t)e * ev.traj_size;
+    int n_app = Lr * ev.napp * 3, n_bod = Lr * ev.nb * 3, n_root = Lr * 3, n_j = Lr * ev.njc;
+    VNL_FOR(k, n_app) {  // get_reference_appendages_pos
+      int t = k / (ev.napp * 3), a = (k / 3) % ev.napp, i = k % 3;
+      tr[k] = ev.body_positions[((fb + t) * ev.nb + ev.app_ref_col[a]) * 3 + i];
+    }
+    VNL_FOR(k, Lr * ev.nb) {  // bodies: local block then global block
+      int t = k / ev.nb, b = k % ev.nb, bd = ev.body_idxs[b];
+      const float* cb = ev.body_positions + ((fb + t) * ev.nb + b) * 3;
+      V3 v = V3{vreal(cb[0]) - s[L.xpos + 3 * bd], vreal(cb[1]) - s[L.xpos + 3 * bd + 1], vreal(cb[2]) - s[L.xpos + 3 * bd + 2]};
+      vreal* lo = tr + n_app + 3 * k;
+      lo[0] = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
+      lo[1] = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
+      lo[2] = v.x * R.a[2] + v.y * R.a[5] + v.z * R.a[8];
+      vreal* gl = tr + n_app + n_bod + 3 * k;
+      gl[0] = v.x, gl[1] = v.y, gl[2] = v.z;
+    }
+    VNL_FOR(t, Lr) {  // root, local
+      const float* cp = ev.position + (fb + t) * 3;
+      V3 v = V3{vreal(cp[0]) - s[L.qpos], vreal(cp[1]) - s[L.qpos + 1], vreal(cp[2]) - s[L.qpos + 2]};
+      vreal* o = tr + n_app + 2 * n_bod + 3 * t;
+      o[0] = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
+      o[1] = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
+      o[2] = v.x * R.a[2] + v.y * R.a[5] + v.z * R.a[8];
+    }
+    VNL_FOR(k, n_j) {  // joints
+      int t = k / ev.njc, col = ev.joint_cols[k % ev.njc];
+      tr[n_app + 2 * n_bod + n_root + k] = vreal(ev.joints[(fb + t) * nj + col]) - s[L.qpos + 7 + col];
+    }
   }
 
   // RodentTracking.reset, rodent.py:119-176 (start_frame / noise supplied by the caller)
   VNL_HD void reset(const int* start_frame, const vreal* noise) const {
+    load_tables();
     int clip = st.clip_id[e], sf = start_frame[e];
     int f = clampi(sf, 0, ev.T - 1), nj = m.nq - 7;
     size_t fb = (size_t)clip * ev.T + f;
-    for (int k = 0; k < 3; k++) ST(qpos, k) = ev.position[fb * 3 + k] + noise[(unsigned)k * B + e];
-    for (int k = 0; k < 4; k++) ST(qpos, 3 + k) = ev.quaternion[fb * 4 + k] + noise[(unsigned)(3 + k) * B + e];
-    for (int k = 0; k < nj; k++) ST(qpos, 7 + k) = ev.joints[fb * nj + k] + noise[(unsigned)(7 + k) * B + e];
-    for (int k = 0; k < 3; k++) ST(qvel, k) = ev.velocity[fb * 3 + k];
-    for (int k = 0; k < 3; k++) ST(qvel, 3 + k) = ev.angular_velocity[fb * 3 + k];
-    for (int k = 0; k < nj; k++) ST(qvel, 6 + k) = ev.joints_velocity[fb * nj + k];
-    for (int i = 0; i < m.nu; i++) ST(act, i) = vreal(0.), W(L.ctrl + i) = vreal(0.);
-    for (int d = 0; d < m.nv; d++) ST(warm, d) = vreal(0.);
-    forward();
+    const vreal* nz = noise + (size_t)e * m.nq;
+    VNL_FOR(k, 3) s[L.qpos + k] = vreal(ev.position[fb * 3 + k]) + nz[k];
+    VNL_FOR(k, 4) s[L.qpos + 3 + k] = vreal(ev.quaternion[fb * 4 + k]) + nz[3 + k];
+    VNL_FOR(k, nj) s[L.qpos + 7 + k] = vreal(ev.joints[fb * nj + k]) + nz[7 + k];
+    VNL_FOR(k, 3) s[L.qvel + k] = ev.velocity[fb * 3 + k];
+    VNL_FOR(k, 3) s[L.qvel + 3 + k] = ev.angular_velocity[fb * 3 + k];
+    VNL_FOR(k, nj) s[L.qvel + 6 + k] = ev.joints_velocity[fb * nj + k];
+    VNL_FOR(i, m.nu) s[L.act + i] = vreal(0.), s[L.ctrl + i] = vreal(0.);
+    VNL_FOR(d, m.nv) s[L.qacc + d] = vreal(0.);
+    VNL_SYNC();
+    forward(s + L.qacc);  // qacc_warmstart = 0 (mjx.make_data)
+    store_state();
     write_traj(clip, sf);
     write_obs();
-    st.reward[e] = vreal(0.), st.done[e] = vreal(0.);
-    for (int k = 0; k < 7; k++) ST(metrics, k) = vreal(0.);
-    st.cur_frame[e] = sf, st.sub_clip_frame[e] = 0;
-    st.term_err[e] = termination(clip, sf);
+    vreal term = termination(clip, sf, s + L.qpos, s + L.xpos);
+    VNL_SERIAL {
+      st.reward[e] = vreal(0.), st.done[e] = vreal(0.);
+      for (int k = 0; k < 7; k++) st.metrics[(size_t)e * 7 + k] = vreal(0.);
+      st.cur_frame[e] = sf, st.sub_clip_frame[e] = 0;
+      st.term_err[e] = term;
+    }
   }
 
   // RodentTracking.step, rodent.py:178-239
   VNL_HD void step(const vreal* action) const {
     prof_begin();
-    int clip = st.clip_id[e], old_frame = st.cur_frame[e];
+    int clip = st.clip_id[e], old_frame = st.cur_frame[e], old_sub = st.sub_clip_frame[e];
+    load_tables();
+    load_state();
     // rtrunk from the OLD pipeline state and OLD frame (rodent.py:250-262, 296)
-    vreal rtrunk = termination(clip, old_frame);
-    for (int i = 0; i < m.nu; i++) {
-      vreal c = action[(unsigned)i * B + e];
+    vreal rtrunk = termination(clip, old_frame, s + L.qpos, st.xpos + (size_t)e * 3 * m.nbody);
+    const vreal* ac = action + (size_t)e * m.nu;
+    VNL_FOR(i, m.nu) {
+      vreal c = ac[i];
       if (m.act_limited[i]) c = fmin(fmax(c, m.act_lo[i]), m.act_hi[i]);
-      W(L.ctrl + i) = c;
+      s[L.ctrl + i] = c;
     }
+    VNL_SYNC();
+    const vreal* gw = st.warm + (size_t)e * m.nv;
     for (int f = 0; f < ev.n_frames; f++) {
-      forward();
+      forward(f == 0 ? gw : s + L.qacc);
       euler();
     }
-    int new_frame = old_frame + 1, new_sub = st.sub_clip_frame[e] + 1;
+    int new_frame = old_frame + 1, new_sub = old_sub + 1;
     int fo = clampi(old_frame, 0, ev.T - 1), nj = m.nq - 7;
     size_t fb = (size_t)clip * ev.T + fo;
     // _calculate_reward: NEW data vs clip row at OLD frame (rodent.py:266-316)
     const float* cb = ev.body_positions + fb * ev.nb * 3;
-    V3 dc = V3{ST(com1, 0) - cb[3 * ev.com_ref_col], ST(com1, 1) - cb[3 * ev.com_ref_col + 1],
-               ST(com1, 2) - cb[3 * ev.com_ref_col + 2]};
-    vreal rcom = exp(-vreal(100.) * sqrt(dot(dc, dc)));
+    V3 dc = V3{s[L.com] - vreal(cb[3 * ev.com_ref_col]), s[L.com + 1] - vreal(cb[3 * ev.com_ref_col + 1]),
+               s[L.com + 2] - vreal(cb[3 * ev.com_ref_col + 2])};
+    vreal rcom = exp(vreal(-100.) * sqrt(dot(dc, dc)));
     vreal acc = vreal(0.);
-    for (int k = 0; k < 3; k++) {
-      vreal a = ST(qvel, k) - ev.velocity[fb * 3 + k], b = ST(qvel, 3 + k) - ev.angular_velocity[fb * 3 + k];
-      acc += a * a + b * b;
-    }
-    for (int k = 0; k < nj; k++) {
-      vreal a = ST(qvel, 6 + k) - ev.joints_velocity[fb * nj + k];
+    VNL_FOR(k, m.nv) {
+      vreal ref = k < 3 ? ev.velocity[fb * 3 + k] : (k < 6 ? ev.angular_velocity[fb * 3 + k - 3] : ev.joints_velocity[fb * nj + k - 6]);
+      vreal a = s[L.qvel + k] - ref;
       acc += a * a;
     }
-    vreal rvel = exp(-vreal(0.1) * sqrt(acc));
+    vreal rvel = exp(vreal(-0.1) * sqrt(vnl_wave_sum(acc)));
     vreal nc = vreal(0.), nr = vreal(0.), dq = vreal(0.);
     for (int k = 0; k < 4; k++) {
-      vreal a = ST(qpos, 3 + k), b = ev.quaternion[fb * 4 + k];
+      vreal a = s[L.qpos + 3 + k], b = ev.quaternion[fb * 4 + k];
       nc += a * a, nr += b * b, dq += a * b;
     }
     dq = dq / (sqrt(nc) * sqrt(nr));
     vreal dist = fmin(vreal(1.), vreal(2.) * dq * dq - vreal(1.));
-    vreal rquat = exp(-vreal(2.) * fabs(vreal(0.5) * acos(dist)));
+    vreal rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
     acc = vreal(0.);
-    for (int d = 0; d < m.nv; d++) acc += ST(qfrc_actuator, d) * ST(qfrc_actuator, d);
-    vreal ract = -vreal(0.015) * (acc / (vreal)m.nv);
+    VNL_FOR(d, m.nv) acc += s[L.qfrc_act + d] * s[L.qfrc_act + d];
+    vreal ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
     acc = vreal(0.);
-    for (int a = 0; a < ev.napp; a++) {
-      int bd = ev.app_body[a], col = ev.app_ref_col[a];
-      for (int k = 0; k < 3; k++) {
-        vreal x = ST(xpos, 3 * bd + k) - cb[3 * col + k];
-        acc += x * x;
-      }
+    VNL_FOR(k, 3 * ev.napp) {
+      int a = k / 3, i = k % 3;
+      vreal x = s[L.xpos + 3 * ev.app_body[a] + i] - vreal(cb[3 * ev.app_ref_col[a] + i]);
+      acc += x * x;
     }
-    vreal rapp = exp(-vreal(400.) * sqrt(acc));
-    vreal z = ST(qpos, 2);
+    vreal rapp = exp(vreal(-400.) * sqrt(vnl_wave_sum(acc)));
+    vreal z = s[L.qpos + 2];
     vreal healthy = (z < ev.healthy_lo || z > ev.healthy_hi) ? vreal(0.) : vreal(1.);
     rcom *= vreal(0.01), rvel *= vreal(0.01), rapp *= vreal(0.01), rtrunk *= vreal(0.01), rquat *= vreal(0.01), ract *= vreal(0.0001);
     vreal total = rcom + rvel + rtrunk + rquat + ract + rapp;
     vreal done = rtrunk < vreal(0.) ? vreal(1.) : vreal(0.);
     done = fmax(vreal(1.) - healthy, done);
     done = fmax(new_sub < ev.sub_clip_length ? vreal(0.) : vreal(1.), done);
-    if (any_nan()) done = vreal(1.);
+    if (store_state()) done = vreal(1.);
     write_obs();
     write_traj(clip, new_frame);
-    st.reward[e] = nan0(total), st.done[e] = done;
-    ST(metrics, 0) = rcom, ST(metrics, 1) = rvel, ST(metrics, 2) = rtrunk, ST(metrics, 3) = rquat;
-    ST(metrics, 4) = ract, ST(metrics, 5) = rapp, ST(metrics, 6) = rtrunk;
-    st.cur_frame[e] = new_frame, st.sub_clip_frame[e] = new_sub;
-    st.term_err[e] = rtrunk;
+    VNL_SERIAL {
+      st.reward[e] = nan0(total), st.done[e] = done;
+      vreal* mt = st.metrics + (size_t)e * 7;
+      mt[0] = rcom, mt[1] = rvel, mt[2] = rtrunk, mt[3] = rquat, mt[4] = ract, mt[5] = rapp, mt[6] = rtrunk;
+      st.cur_frame[e] = new_frame, st.sub_clip_frame[e] = new_sub;
+      st.term_err[e] = rtrunk;
+    }
     VNL_PROF(14);
     prof_end();
   }
-#undef ST
+
+  // bisection hook: copy this env's LDS image to a global dump [env][L.total]
+  VNL_HD void dump(vreal* out) const {
+    VNL_SYNC();
+    VNL_FOR(k, L.total) out[(size_t)e * L.total + k] = s[k];
+  }
 };

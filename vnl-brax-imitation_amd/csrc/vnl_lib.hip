@@ -105,10 +105,11 @@ struct vnl_env {
   DevModel dm{};
   DevEnv de{};
   WsLayout L{};
-  vreal* ws = nullptr;
+  vreal* dump = nullptr;  // [B][L.total] image of the per-env LDS, written only when debug is on
+  int debug = 0;
+  size_t lds_bytes = 0;
   std::vector<void*> allocs;
   std::map<std::string, std::pair<int, int>> sections;  // name -> (offset, count)
-  int block = 64;
 };
 
 template <class T, class S>
@@ -142,7 +143,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     size_t n;
     bool isint;
   } needs[] = {{"body_parentid", (size_t)nb, true}, {"body_jntadr", (size_t)nb, true}, {"body_jntnum", (size_t)nb, true},
-               {"body_rootid", (size_t)nb, true}, {"body_pos", 3u * nb, false}, {"body_quat", 4u * nb, false},
+               {"body_rootid", (size_t)nb, true}, {"body_dofadr", (size_t)nb, true}, {"body_dofnum", (size_t)nb, true}, {"body_pos", 3u * nb, false}, {"body_quat", 4u * nb, false},
                {"body_ipos", 3u * nb, false}, {"body_inertia_full", 9u * nb, false}, {"body_mass", (size_t)nb, false},
                {"body_invweight0", 2u * nb, false}, {"jnt_type", (size_t)nj, true}, {"jnt_qposadr", (size_t)nj, true},
                {"jnt_dofadr", (size_t)nj, true}, {"jnt_limited", (size_t)nj, true}, {"jnt_pos", 3u * nj, false},
@@ -194,6 +195,44 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
 #define UPF(name, vec) if ((rc = upload<vreal, double>(env, vec, &d.name)) != VNL_OK) return rc;
 #define UPI(name, vec) if ((rc = upload<int, int>(env, vec, &d.name)) != VNL_OK) return rc;
   UPI(body_parent, I("body_parentid")) UPI(body_jntadr, I("body_jntadr")) UPI(body_jntnum, I("body_jntnum"))
+  {
+    std::vector<int> da(nb, 0), dn(nb, 0);
+    for (int b = 0; b < nb; b++) {
+      dn[b] = I("body_dofnum")[b];
+      da[b] = dn[b] > 0 ? I("body_dofadr")[b] : 0;
+    }
+    UPI(body_dofadr, da) UPI(body_dofnum, dn)
+    // subtree sizes (bodies are numbered depth-first: subtree(b) = b .. b + nsub[b]) and the
+    // pointer-jumping tables jump[r][b] = 2^r-th ancestor of b (0 when it would be the world body)
+    const auto& bp = I("body_parentid");
+    std::vector<int> nsub(nb, 0);
+    for (int b = nb - 1; b > 0; b--) nsub[bp[b]] += nsub[b] + 1;
+    for (int b = 1; b < nb; b++)
+      for (int c = b + 1; c <= b + nsub[b]; c++) {
+        bool in = false;
+        for (int a = c; a > 0; a = bp[a]) in |= (a == b);
+        if (!in) return fail(VNL_ERR_UNSUPPORTED, "body numbering is not depth-first");
+      }
+    UPI(body_nsub, nsub)
+    int bdepth = 0;
+    for (int b = 1; b < nb; b++) {
+      int dd = 0;
+      for (int a = b; a > 0; a = bp[a]) dd++;
+      bdepth = dd > bdepth ? dd : bdepth;
+    }
+    int rounds = 0;
+    while ((1 << rounds) < bdepth) rounds++;
+    d.jump_rounds = rounds;
+    std::vector<unsigned char> jump((size_t)(rounds > 0 ? rounds : 1) * nb, 0);
+    for (int b = 0; b < nb; b++) jump[b] = (unsigned char)bp[b];
+    for (int r = 1; r < rounds; r++)
+      for (int b = 0; b < nb; b++) jump[(size_t)r * nb + b] = jump[(size_t)(r - 1) * nb + jump[(size_t)(r - 1) * nb + b]];
+    {
+      const unsigned char* dp = nullptr;
+      if ((rc = upload<unsigned char, unsigned char>(env, jump, &dp)) != VNL_OK) return rc;
+      d.jump = dp;
+    }
+  }
   UPF(body_pos, F("body_pos")) UPF(body_quat, F("body_quat")) UPF(body_ipos, F("body_ipos")) UPF(body_mass, F("body_mass"))
   {
     std::vector<double> i6(6 * (size_t)nb);
@@ -237,7 +276,46 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       depth[i] = dep - 1;
     }
     d.nM = (int)anc.size();
-    UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc)
+    std::vector<int> row(anc.size());
+    for (int i = 0; i < nv; i++)
+      for (int a = 0; a <= depth[i]; a++) row[madr[i] + a] = i;
+    // descendants of a dof are the next ndesc dofs (DFS numbering); checked here because col_apply relies on it
+    std::vector<int> ndesc(nv, 0);
+    for (int i = 0; i < nv; i++)
+      for (int j = par[i]; j >= 0; j = par[j]) ndesc[j]++;
+    for (int a = 0; a < nv; a++)
+      for (int i = a + 1; i <= a + ndesc[a]; i++) {
+        bool is_desc = false;
+        for (int j = par[i]; j >= 0; j = par[j]) is_desc |= (j == a);
+        if (!is_desc) return fail(VNL_ERR_UNSUPPORTED, "dof numbering is not depth-first");
+      }
+    int maxd = 0;
+    for (int i = 0; i < nv; i++) maxd = depth[i] > maxd ? depth[i] : maxd;
+    d.max_depth = maxd;
+    if (nv > 255 || nb > 255 || maxd > 254) return fail(VNL_ERR_UNSUPPORTED, "model too large for 8-bit index tables");
+    std::vector<int> tri;  // pairs (a, sidx = a + c), ordered by sidx then a: a prefix enumerates any depth
+    for (int sidx = 1; sidx <= maxd; sidx++)
+      for (int a = 1; a <= sidx; a++) tri.push_back(a | (sidx << 8));
+    std::vector<int> lvl_ptr(maxd + 2, 0), lvl_entry;
+    int max_level = 0;
+    for (int lev = 0; lev <= maxd; lev++) {
+      lvl_ptr[lev] = (int)lvl_entry.size();
+      for (int i = 0; i < nv; i++)
+        if (depth[i] == lev)
+          for (int t = 1; t <= depth[i]; t++) lvl_entry.push_back(madr[i] + t);
+      int cnt = (int)lvl_entry.size() - lvl_ptr[lev];
+      max_level = cnt > max_level ? cnt : max_level;
+    }
+    lvl_ptr[maxd + 1] = (int)lvl_entry.size();
+    if (max_level > 3 * nv) return fail(VNL_ERR_UNSUPPORTED, "tree level too wide for the inversion staging buffer");
+    std::vector<int> limrow(nv, -1);
+    {
+      int r = 0;
+      for (int j = 0; j < nj; j++)
+        if (I("jnt_limited")[j] && jt[j] == VNL_JNT_HINGE) limrow[I("jnt_dofadr")[j]] = r++;
+    }
+    UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc) UPI(M_row, row)
+    UPI(dof_ndesc, ndesc) UPI(tri, tri) UPI(lvl_ptr, lvl_ptr) UPI(lvl_entry, lvl_entry) UPI(dof_limrow, limrow)
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
@@ -248,6 +326,12 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     UPF(act_lo, lo) UPF(act_hi, hi)
   }
   UPI(cg_type, I("cg_type")) UPI(cg_body, I("cg_bodyid")) UPI(cg_conadr, I("cg_conadr")) UPI(cg_ncon, I("cg_ncon"))
+  {
+    std::vector<int> cgeom(d.ncon, 0);
+    for (int g = 0; g < ng; g++)
+      for (int q = 0; q < I("cg_ncon")[g]; q++) cgeom[I("cg_conadr")[g] + q] = g;
+    UPI(con_geom, cgeom)
+  }
   UPF(cg_pos, F("cg_pos")) UPF(cg_quat, F("cg_quat")) UPF(cg_size, F("cg_size")) UPF(cg_solref, F("cg_solref"))
   UPF(cg_solimp, F("cg_solimp")) UPF(cg_margin, F("cg_margin"))
   {
@@ -275,19 +359,27 @@ static void layout(vnl_env* env) {
     o += n;
     return at;
   };
-  L.ctrl = sec("ctrl", d.nu), L.actdot = sec("act_dot", d.nu);
-  L.cdof = sec("cdof", 6 * d.nv), L.cinert = sec("cinert", 10 * d.nbody);
-  L.M = sec("qM", d.nM), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
-  L.bodyA = sec("bodyA", 10 * d.nbody), L.bodyB = sec("bodyB", 12 * d.nbody), L.bodyC = sec("bodyC", 12 * d.nbody);
+  L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
+  L.actdot = sec("act_dot", d.nu), L.xpos = sec("xpos", 3 * d.nbody), L.xquat = sec("xquat", 4 * d.nbody);
+  L.com = sec("subtree_com1", 4);
+  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
+  L.T1 = sec("T1", 10 * d.nbody);
+  L.T2 = sec("T2", 6 * d.nbody + 6 * (d.nbody > d.nv ? d.nbody : d.nv));
   L.bias = sec("qfrc_bias", d.nv), L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv);
   L.qacc = sec("qacc", d.nv), L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv);
   L.search = sec("search", d.nv), L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv);
-  L.tmp = sec("tmp", d.nv);
+  L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv), L.qfrc_act = sec("qfrc_actuator", d.nv);
   L.con_dist = sec("con_dist", d.ncon), L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncon);
   L.lim_sign = sec("lim_sign", d.nlimit);
-  L.efc_D = sec("efc_D", d.nefc), L.efc_aref = sec("efc_aref", d.nefc), L.Jaref = sec("Jaref", d.nefc);
-  L.jv = sec("jv", d.nefc);
-  L.total = o;
+  L.efc_D = sec("efc_D", d.nefc);
+  // Jaref | jv are contiguous: together they double as cfrc (6*nbody) during the bias pass
+  int pad = 6 * d.nbody > 2 * d.nefc ? 6 * d.nbody - 2 * d.nefc : 0;
+  L.Jaref = sec("Jaref", d.nefc), L.jv = sec("jv", d.nefc + pad);
+  auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
+  L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
+  L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + d.ncon));
+  L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));
+  L.total = (o + 3) & ~3;
 }
 
 extern "C" void vnl_env_destroy(vnl_env* env) {
@@ -351,26 +443,11 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   UP(upload_raw<float>(env, es->joints_velocity, CT * nj, &e.joints_velocity))
 #undef UP
   layout(env);
-  size_t wsbytes = (size_t)env->L.total * num_envs * sizeof(vreal);
-  if ((size_t)env->L.total * num_envs >= (1ull << 31)) {
+  env->lds_bytes = (size_t)env->L.total * sizeof(vreal);
+  if (env->lds_bytes > 64 * 1024) {
     vnl_env_destroy(env);
-    return fail(VNL_ERR_ARG, "num_envs too large for 32-bit scratch indexing");
+    return fail(VNL_ERR_UNSUPPORTED, "model too large: per-env working set exceeds 64 KB of LDS");
   }
-  void* p = nullptr;
-  hipError_t he = hipMalloc(&p, wsbytes);
-  if (he != hipSuccess) {
-    vnl_env_destroy(env);
-    return fail(VNL_ERR_HIP, "hipMalloc(scratch): %s", hipGetErrorString(he));
-  }
-  env->allocs.push_back(p);
-  env->ws = (vreal*)p;
-  he = hipMemset(p, 0, wsbytes);
-  if (he != hipSuccess) {
-    vnl_env_destroy(env);
-    return fail(VNL_ERR_HIP, "hipMemset(scratch): %s", hipGetErrorString(he));
-  }
-  const char* bs = getenv("VNL_BLOCK");
-  if (bs && atoi(bs) > 0 && atoi(bs) % 64 == 0 && atoi(bs) <= 256) env->block = atoi(bs);
   *out = env;
   return VNL_OK;
 }
@@ -388,28 +465,42 @@ extern "C" int vnl_env_scratch(const vnl_env* env, const char* name, float** dev
   if (!env || !name || !dev_ptr || !count) return fail(VNL_ERR_ARG, "vnl_env_scratch: null argument");
   auto it = env->sections.find(name);
   if (it == env->sections.end()) return fail(VNL_ERR_ARG, "unknown scratch section %s", name);
-  *dev_ptr = (float*)(env->ws + (size_t)it->second.first * env->B);
+  if (!env->dump) return fail(VNL_ERR_ARG, "scratch dump is off: call vnl_env_debug(env, 1) before reset/step");
+  *dev_ptr = (float*)(env->dump + it->second.first);
   *count = it->second.second;
   return VNL_OK;
 }
 
-// ----------------------------------------------------------------------------- kernels
-// One env per lane.  64-thread workgroups: at 4096 envs the grid is 64 waves, one per CU,
-// so each wave owns a CU's scheduler, L1 and scalar cache (occupancy note).
-__global__ void __launch_bounds__(256) vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, vreal* ws,
-                                                        const vreal* action, unsigned B) {
-  unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B) return;
-  EnvLane lane{m, ev, st, L, ws, B, e};
-  lane.step(action);
+extern "C" int vnl_env_debug(vnl_env* env, int32_t enable, int32_t* row_stride) {
+  if (!env) return fail(VNL_ERR_ARG, "vnl_env_debug: null argument");
+  if (enable && !env->dump) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t)env->L.total * env->B * sizeof(vreal)));
+    env->allocs.push_back(p);
+    env->dump = (vreal*)p;
+  }
+  env->debug = enable ? 1 : 0;
+  if (row_stride) *row_stride = env->L.total;
+  return VNL_OK;
 }
 
-__global__ void __launch_bounds__(256) vnl_reset_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, vreal* ws,
-                                                         const int* start_frame, const vreal* noise, unsigned B) {
-  unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B) return;
-  EnvLane lane{m, ev, st, L, ws, B, e};
-  lane.reset(start_frame, noise);
+// ----------------------------------------------------------------------------- kernels
+// One env per 64-lane workgroup; the env's whole working set lives in dynamic LDS (~25 KB ->
+// 6 workgroups per CU, 1536 envs in flight on 256 CUs).
+__global__ void __launch_bounds__(64) vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L,
+                                                      const vreal* action, vreal* dump) {
+  VNL_LDS_DECL(lds);
+  EnvWave w{m, ev, st, L, lds, blockIdx.x, threadIdx.x};
+  w.step(action);
+  if (dump) w.dump(dump);
+}
+
+__global__ void __launch_bounds__(64) vnl_reset_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L,
+                                                       const int* start_frame, const vreal* noise, vreal* dump) {
+  VNL_LDS_DECL(lds);
+  EnvWave w{m, ev, st, L, lds, blockIdx.x, threadIdx.x};
+  w.reset(start_frame, noise);
+  if (dump) w.dump(dump);
 }
 
 static int to_dev_state(const vnl_state* s, DevState* d) {
@@ -434,9 +525,8 @@ extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const flo
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
-  unsigned B = env->B, grid = (B + env->block - 1) / env->block;
-  hipLaunchKernelGGL(vnl_reset_kernel, dim3(grid), dim3(env->block), 0, (hipStream_t)stream, env->dm, env->de, ds,
-                     env->L, env->ws, (const int*)start_frame, (const vreal*)noise, B);
+  hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream, env->dm, env->de,
+                     ds, env->L, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }
@@ -446,9 +536,8 @@ extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* 
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
-  unsigned B = env->B, grid = (B + env->block - 1) / env->block;
-  hipLaunchKernelGGL(vnl_step_kernel, dim3(grid), dim3(env->block), 0, (hipStream_t)stream, env->dm, env->de, ds,
-                     env->L, env->ws, (const vreal*)action, B);
+  hipLaunchKernelGGL(vnl_step_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream, env->dm, env->de,
+                     ds, env->L, (const vreal*)action, env->debug ? env->dump : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

@@ -1,6 +1,4 @@
-// Device-side tables passed to the kernels BY VALUE (kernarg segment -> SGPRs).
-// Every table pointer is read with wave-uniform indices, so hipcc emits scalar
-// loads (s_load_*) through the constant cache; no LDS staging is needed for them.
+// Device-side tables passed to the kernels BY VALUE (kernarg segment).
 #pragma once
 #include <stdint.h>
 
@@ -20,7 +18,7 @@ typedef VNL_REAL vreal;
 
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
-  int iterations, ls_iterations, eulerdamp, root_free;
+  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
   vreal pnx, pny, pnz, ppx, ppy, ppz; /* plane normal / point */
@@ -28,7 +26,8 @@ struct DevModel {
   vreal total_mass_inv;
   vreal root_px, root_py, root_pz; /* reference point when the root is not a free joint */
   // bodies
-  const int *body_parent, *body_jntadr, *body_jntnum;
+  const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub;
+  const unsigned char* jump; /* [jump_rounds][nbody]: 2^r-th ancestor body, 0 = none */
   const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
   // joints
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr;
@@ -36,14 +35,18 @@ struct DevModel {
   // limit rows (one per limited hinge)
   const int *lim_qadr, *lim_dof;
   const vreal *lim_lo, *lim_hi, *lim_margin, *lim_invweight, *lim_solref, *lim_solimp;
-  // dofs
-  const int *dof_body, *dof_Madr, *dof_depth, *M_anc;
+  // dofs; tree-sparse qM layout (MuJoCo dof_Madr order: self, parent, grandparent, ...)
+  const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
+  const int *M_anc, *M_row;          /* per entry: column dof / row dof */
+  const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
+  const int *tri;                    /* universal (a | (a+c) << 8) enumeration of factor update pairs */
+  const int *lvl_ptr, *lvl_entry;    /* strictly-lower entries grouped by depth of their row dof */
   const vreal *dof_armature, *dof_damping;
   // actuators
   const int *act_dof, *act_limited;
   const vreal *act_gain, *act_tau, *act_lo, *act_hi, *act_gear;
-  // collidable geoms (all against the one plane)
-  const int *cg_type, *cg_body, *cg_conadr, *cg_ncon;
+  // collidable geoms (all against the one plane); contact c belongs to geom con_geom[c]
+  const int *cg_type, *cg_body, *cg_conadr, *cg_ncon, *con_geom;
   const vreal *cg_pos, *cg_quat, *cg_size, *cg_mu, *cg_solref, *cg_solimp, *cg_margin, *cg_invweight;
 };
 
@@ -55,22 +58,24 @@ struct DevEnv {
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
 };
 
-// caller-owned SoA buffers (see include/vnl.h vnl_state)
+// caller-owned buffers, row-major [env][feature] (see include/vnl.h vnl_state)
 struct DevState {
   vreal *qpos, *qvel, *act, *warm, *xpos, *xquat, *com1, *qfrc_actuator;
   vreal *obs, *reward, *done, *metrics, *traj, *term_err;
   int *cur_frame, *sub_clip_frame, *clip_id;
 };
 
-// per-env scratch sections (offsets in floats; element k of section s for env e
-// lives at ws[(s + k) * B + e])
+// per-env LDS sections (offsets in vreal elements)
 struct WsLayout {
-  int ctrl, actdot;
-  int cdof, cinert, M, LD, dinv;
-  int bodyA, bodyB, bodyC; /* 3 x (10*nbody): crb | cvel,cacc,cfrc | V, F/W */
-  int bias, smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp;
+  int qpos, qvel, act, ctrl, actdot, xpos, xquat, com;
+  int cdof, LD, dinv;
+  int T1;  /* 10*nbody: cinert -> crb | per-contact wrenches in the solver */
+  int T2;  /* 12*nbody: cvel | cacc (-> per-dof crb*cdof) ; in the solver: twists V | wrenches W */
+  int bias, smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2, qfrc_act;
+  int tab_anc, tab_madr, tab_E, tab_body; /* index tables (bytes / ints) staged in LDS */
+  int act_list;                           /* ncon bytes: contacts with D != 0, then their count (int) */
   int con_dist, con_r, con_t1;
   int lim_sign;
-  int efc_D, efc_aref, Jaref, jv;
+  int efc_D, Jaref, jv; /* Jaref|jv doubles as cfrc (6*nbody) during the bias pass */
   int total;
 };

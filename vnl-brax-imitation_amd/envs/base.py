@@ -5,9 +5,8 @@ metrics, info) as used at reference envs/rodent.py:166,237-239; `PipelineState`
 exposes the mjx.Data fields the reference env reads (qpos, qvel, xpos, xmat,
 subtree_com, qfrc_actuator, q, qd: rodent.py:250-314,335-341).
 
-Storage is structure-of-arrays [feature][env] (what the kernels read and write
-with coalesced wave accesses); every public attribute is the transposed VIEW
-(env-major, e.g. obs -> (B, 232)), no copies.
+Storage is row-major [env][feature] -- plain (B, n) tensors, exactly what the kernels
+read and write (one wavefront per env, lanes across the feature axis).
 """
 from __future__ import annotations
 
@@ -31,28 +30,28 @@ class PipelineState:
     def allocate(dims, B: int, device, dtype=torch.float32) -> "PipelineState":
         n = dict(qpos=dims.nq, qvel=dims.nv, act=dims.nu, qacc_warmstart=dims.nv, xpos=3 * dims.nbody,
                  xquat=4 * dims.nbody, subtree_com1=3, qfrc_actuator=dims.nv)
-        return PipelineState({k: torch.zeros((v, B), dtype=dtype, device=device) for k, v in n.items()})
+        return PipelineState({k: torch.zeros((B, v), dtype=dtype, device=device) for k, v in n.items()})
 
-    def soa(self, name: str) -> torch.Tensor:
+    def raw(self, name: str) -> torch.Tensor:
         return self._soa[name]
 
-    qpos = property(lambda s: s._soa["qpos"].T)
-    qvel = property(lambda s: s._soa["qvel"].T)
+    qpos = property(lambda s: s._soa["qpos"])
+    qvel = property(lambda s: s._soa["qvel"])
     q = qpos
     qd = qvel
-    act = property(lambda s: s._soa["act"].T)
-    qacc_warmstart = property(lambda s: s._soa["qacc_warmstart"].T)
-    qfrc_actuator = property(lambda s: s._soa["qfrc_actuator"].T)
+    act = property(lambda s: s._soa["act"])
+    qacc_warmstart = property(lambda s: s._soa["qacc_warmstart"])
+    qfrc_actuator = property(lambda s: s._soa["qfrc_actuator"])
 
     @property
     def xpos(self) -> torch.Tensor:  # (B, nbody, 3)
         t = self._soa["xpos"]
-        return t.T.reshape(t.shape[1], -1, 3)
+        return t.view(t.shape[0], -1, 3)
 
     @property
     def xquat(self) -> torch.Tensor:  # (B, nbody, 4)
         t = self._soa["xquat"]
-        return t.T.reshape(t.shape[1], -1, 4)
+        return t.view(t.shape[0], -1, 4)
 
     @property
     def xmat(self) -> torch.Tensor:  # (B, nbody, 3, 3), computed on demand from xquat
@@ -66,7 +65,7 @@ class PipelineState:
 
     @property
     def subtree_com_root(self) -> torch.Tensor:  # (B, 3) == data.subtree_com[1]
-        return self._soa["subtree_com1"].T
+        return self._soa["subtree_com1"]
 
     def clone(self) -> "PipelineState":
         return PipelineState({k: v.clone() for k, v in self._soa.items()})
@@ -76,7 +75,7 @@ class PipelineState:
             if mask is None:
                 v.copy_(other._soa[k])
             else:
-                torch.where(mask[None, :], other._soa[k], v, out=v)
+                torch.where(mask[:, None], other._soa[k], v, out=v)
 
 
 @dataclasses.dataclass

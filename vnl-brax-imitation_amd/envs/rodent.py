@@ -210,20 +210,20 @@ class RodentTracking(Env):
     def _alloc_state(self) -> State:
         B, dv, d = self.num_envs, self.device, self.dims
         ps = PipelineState.allocate(d, B, dv, self._dtype)
-        z = lambda n, dt=self._dtype: torch.zeros((n, B), dtype=dt, device=dv)  # noqa: E731
-        raw = dict(obs=z(d.obs_size), reward=z(1), done=z(1), metrics=z(7), traj=z(d.traj_size),
-                   termination_error=z(1), cur_frame=z(1, torch.int32), sub_clip_frame=z(1, torch.int32),
-                   clip_id=z(1, torch.int32))
-        metrics = {k: raw["metrics"][i] for i, k in enumerate(_METRICS)}
-        info = dict(cur_frame=raw["cur_frame"][0], sub_clip_frame=raw["sub_clip_frame"][0], traj=raw["traj"].T,
-                    termination_error=raw["termination_error"][0], clip_id=raw["clip_id"][0], _raw=raw)
-        return State(ps, raw["obs"].T, raw["reward"][0], raw["done"][0], metrics, info)
+        z = lambda n, dt=self._dtype: torch.zeros((B, n) if n else (B,), dtype=dt, device=dv)  # noqa: E731
+        raw = dict(obs=z(d.obs_size), reward=z(0), done=z(0), metrics=z(7), traj=z(d.traj_size),
+                   termination_error=z(0), cur_frame=z(0, torch.int32), sub_clip_frame=z(0, torch.int32),
+                   clip_id=z(0, torch.int32))
+        metrics = {k: raw["metrics"][:, i] for i, k in enumerate(_METRICS)}
+        info = dict(cur_frame=raw["cur_frame"], sub_clip_frame=raw["sub_clip_frame"], traj=raw["traj"],
+                    termination_error=raw["termination_error"], clip_id=raw["clip_id"], _raw=raw)
+        return State(ps, raw["obs"], raw["reward"], raw["done"], metrics, info)
 
     def _ptrs(self, state: State) -> _lib.StatePtrs:
         raw, ps = state.info["_raw"], state.pipeline_state
         p = _lib.StatePtrs()
         for k in PipelineState._FIELDS:
-            setattr(p, k, ps.soa(k).data_ptr())
+            setattr(p, k, ps.raw(k).data_ptr())
         for k in ("obs", "reward", "done", "metrics", "traj", "termination_error", "cur_frame", "sub_clip_frame",
                   "clip_id"):
             setattr(p, k, raw[k].data_ptr())
@@ -250,8 +250,8 @@ class RodentTracking(Env):
                        torch.randint(0, self._num_clips, (B,), generator=gen, dtype=torch.int32))
         state = out if out is not None else self._alloc_state()
         sf = torch.as_tensor(start_frame, dtype=torch.int32).to(self.device).contiguous()
-        nz = torch.as_tensor(noise).to(device=self.device, dtype=self._dtype).T.contiguous()  # SoA [nq][B]
-        state.info["_raw"]["clip_id"][0].copy_(torch.as_tensor(clip_id, dtype=torch.int32).to(self.device))
+        nz = torch.as_tensor(noise).to(device=self.device, dtype=self._dtype).contiguous()  # [B][nq]
+        state.info["_raw"]["clip_id"].copy_(torch.as_tensor(clip_id, dtype=torch.int32).to(self.device))
         p = self._ptrs(state)
         _lib.check(self._L, self._L.vnl_env_reset(self._env_h, sf.data_ptr(), nz.data_ptr(), C.byref(p),
                                                   self._stream()))
@@ -259,14 +259,11 @@ class RodentTracking(Env):
         return state
 
     def step(self, state: State, action: torch.Tensor) -> State:
-        """rodent.py:178-239.  action: (B, nu) env-major or its SoA transpose (nu, B) contiguous."""
+        """rodent.py:178-239.  action: (B, nu)."""
         nu, B = int(self.dims.nu), self.num_envs
-        a = action
-        if a.shape == (B, nu):
-            a = a.T
-        if a.shape != (nu, B):
+        if tuple(action.shape) != (B, nu):
             raise ValueError(f"action must be ({B},{nu}), got {tuple(action.shape)}")
-        a = a.to(device=self.device, dtype=self._dtype).contiguous()
+        a = action.to(device=self.device, dtype=self._dtype).contiguous()
         p = self._ptrs(state)
         ev = getattr(self, "kernel_events", None)  # (start, end) torch.cuda.Event pair, used by bench.py
         if ev is not None:
@@ -278,23 +275,30 @@ class RodentTracking(Env):
         return state
 
     # --- bisection hook -----------------------------------------------------------------------
+    def debug(self, enable: bool = True) -> None:
+        """With debug on, every reset/step also dumps the per-env LDS image for `scratch()`."""
+        stride = C.c_int32()
+        _lib.check(self._L, self._L.vnl_env_debug(self._env_h, int(enable), C.byref(stride)))
+        self._dump_stride = stride.value
+
     def scratch(self, name: str) -> torch.Tensor:
-        """(B, count) copy of a named per-env scratch section left by the last reset/step."""
+        """(B, count) copy of a named per-env scratch section left by the last reset/step (debug on)."""
         ptr, cnt = C.c_void_p(), C.c_int32()
         _lib.check(self._L, self._L.vnl_env_scratch(self._env_h, name.encode(), C.byref(ptr), C.byref(cnt)))
-        n = cnt.value * self.num_envs
+        B, n, stride = self.num_envs, cnt.value, self._dump_stride
+        esz = 8 if self._dtype == torch.float64 else 4
+        total = (B - 1) * stride + n
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-            out = torch.empty((cnt.value, self.num_envs), dtype=torch.float32, device=self.device)
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), ptr, C.c_size_t(4 * n), C.c_int(3))
+            flat = torch.empty(total, dtype=self._dtype, device=self.device)
+            hip = C.CDLL("libamdhip64.so")
+            rc = hip.hipMemcpy(C.c_void_p(flat.data_ptr()), ptr, C.c_size_t(esz * total), C.c_int(3))
             if rc != 0:
                 raise _lib.VnlError(f"hipMemcpy failed: {rc}")
-            return out.T.contiguous()
-        ct = C.c_double if self._dtype == torch.float64 else C.c_float
-        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(cnt.value, self.num_envs))
-        return torch.from_numpy(arr.copy()).T.contiguous()
+        else:
+            ct = C.c_double if self._dtype == torch.float64 else C.c_float
+            flat = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(total,)).copy())
+        return torch.as_strided(flat, (B, n), (stride, 1)).contiguous()
 
 
 class RodentMultiClipTracking(RodentTracking):

@@ -89,7 +89,7 @@ class AutoResetWrapper(Wrapper):
     def reset(self, rng=None, **kw) -> State:
         state = self.env.reset(rng, **kw)
         state.info["first_pipeline_state"] = state.pipeline_state.clone()
-        state.info["first_obs"] = state.obs.clone()  # env-major copy
+        state.info["first_obs"] = state.obs.clone()
         if self.reset_info:
             state.info["first_info"] = {k: state.info[k].clone() for k in ("cur_frame", "sub_clip_frame", "traj")}
         return state
