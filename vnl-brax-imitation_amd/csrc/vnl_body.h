@@ -179,6 +179,9 @@ struct EnvWave {
   VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
   VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
   VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + c]; }
+  // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
+  VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
+  VNL_HD int lvl_start(int l) const { return ((const unsigned char*)(s + L.tab_lvl))[m.nv + l]; }
   VNL_HD void load_tables() const {
     unsigned char* ta = (unsigned char*)(s + L.tab_anc);
     VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
@@ -192,21 +195,46 @@ struct EnvWave {
       tb[2 * m.nbody + b] = (unsigned char)m.body_dofnum[b];
     }
     VNL_FOR(c, m.ncon) tb[3 * m.nbody + c] = (unsigned char)m.cg_body[m.con_geom[c]];
+    unsigned char* tl = (unsigned char*)(s + L.tab_lvl);
+    VNL_FOR(q, m.nv + m.max_depth + 2) tl[q] = m.lvl_tab[q];
     VNL_SYNC();
   }
 
   // ------------------------------------------------------------------ kinematics
-  // smooth.kinematics + cdof in one tree walk (one lane), reference point O.
+  // Tree prefix by pointer jumping: on entry buf0[6b+k] holds each body's own contribution; on exit
+  // the returned buffer holds the sum over the body's whole ancestor path.  jump_r[b] = 2^r-th
+  // ancestor (0 = none), log2(depth) rounds, ping-pong between buf0 and buf1.
+  VNL_HD int tree_prefix(int buf0, int buf1) const {
+    int src = buf0, dst = buf1;
+    for (int r = 0; r < m.jump_rounds; r++) {
+      const unsigned char* jr = m.jump + r * m.nbody;
+      VNL_FOR(i, 6 * m.nbody) {
+        int b = i / 6, j = jr[b];
+        vreal v = s[src + i];
+        if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
+        s[dst + i] = v;
+      }
+      VNL_SYNC();
+      int t = src;
+      src = dst, dst = t;
+    }
+    return src;
+  }
+
+  // smooth.kinematics in three fork-join phases:
+  //  (1) per body, in parallel: its transform relative to the parent frame as a function of its own
+  //      joint angles (MJX's anchor / off-centre rotation rule applied in the parent frame), plus the
+  //      joint anchors / axes in that frame;
+  //  (2) world poses = composition of the local transforms along each ancestor path, by pointer
+  //      jumping (log2(depth) rounds) -- composition of rigid transforms is associative;
+  //  (3) per dof, in parallel: cdof from the parent's world pose and the local anchor / axis.
   VNL_HD void kinematics() const {
-    VNL_SERIAL {
-      V3 O = ref_point();
-      st3(L.xpos, v3(vreal(0.), vreal(0.), vreal(0.)));
-      s[L.xquat] = vreal(1.), s[L.xquat + 1] = vreal(0.), s[L.xquat + 2] = vreal(0.), s[L.xquat + 3] = vreal(0.);
-      for (int b = 1; b < m.nbody; b++) {
-        int p = m.body_parent[b];
-        Q4 pq = ld4(L.xquat + 4 * p);
-        V3 pos = ld3(L.xpos + 3 * p) + qrot(t3(m.body_pos, b), pq);
-        Q4 quat = qmul(pq, t4(m.body_quat, b));
+    int A = L.T1, Bf = L.T2;  // 7 floats per body: pos(3) quat(4)
+    VNL_FOR(b, m.nbody) {
+      V3 pos = v3(vreal(0.), vreal(0.), vreal(0.));
+      Q4 quat = Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)};
+      if (b > 0) {
+        pos = t3(m.body_pos, b), quat = t4(m.body_quat, b);
         int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
         for (int k = 0; k < jn; k++) {
           int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
@@ -218,32 +246,68 @@ struct EnvWave {
             quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
             s[L.qpos + qa + 3] = quat.w, s[L.qpos + qa + 4] = quat.x, s[L.qpos + qa + 5] = quat.y,
                             s[L.qpos + qa + 6] = quat.z;  // normalised quaternion written back
-            M3 R = qmat(quat);
-            V3 off = O - pos;
-            for (int t = 0; t < 3; t++) {
-              int o = L.cdof + 6 * (da + t);
-              s[o] = vreal(0.), s[o + 1] = vreal(0.), s[o + 2] = vreal(0.);
-              s[o + 3] = t == 0 ? vreal(1.) : vreal(0.), s[o + 4] = t == 1 ? vreal(1.) : vreal(0.),
-                    s[o + 5] = t == 2 ? vreal(1.) : vreal(0.);
-            }
-            for (int t = 0; t < 3; t++) {
-              V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
-              st6(L.cdof + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
-            }
           } else {
             V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
             V3 anchor = qrot(jp, quat) + pos;
-            V3 axis = qrot(jax, quat);
+            st6(L.cdof + 6 * da, S6{qrot(jax, quat), anchor});  // (axis, anchor) in the parent frame, for phase 3
             vreal ang = s[L.qpos + qa] - m.jnt_qpos0[j];
             vreal sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
             quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
             pos = anchor - qrot(jp, quat);
-            st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
           }
         }
-        st3(L.xpos + 3 * b, pos);
-        s[L.xquat + 4 * b] = quat.w, s[L.xquat + 4 * b + 1] = quat.x, s[L.xquat + 4 * b + 2] = quat.y,
-                        s[L.xquat + 4 * b + 3] = quat.z;
+      }
+      st3(A + 7 * b, pos);
+      s[A + 7 * b + 3] = quat.w, s[A + 7 * b + 4] = quat.x, s[A + 7 * b + 5] = quat.y, s[A + 7 * b + 6] = quat.z;
+    }
+    VNL_SYNC();
+    int src = A, dst = Bf;
+    for (int r = 0; r < m.jump_rounds; r++) {
+      const unsigned char* jr = m.jump + r * m.nbody;
+      VNL_FOR(b, m.nbody) {
+        int j = jr[b];
+        V3 pos = ld3(src + 7 * b);
+        Q4 quat = ld4(src + 7 * b + 3);
+        if (j > 0) {  // X_b <- X_j o X_b
+          Q4 pq = ld4(src + 7 * j + 3);
+          pos = ld3(src + 7 * j) + qrot(pos, pq);
+          quat = qmul(pq, quat);
+        }
+        st3(dst + 7 * b, pos);
+        s[dst + 7 * b + 3] = quat.w, s[dst + 7 * b + 4] = quat.x, s[dst + 7 * b + 5] = quat.y, s[dst + 7 * b + 6] = quat.z;
+      }
+      VNL_SYNC();
+      int t = src;
+      src = dst, dst = t;
+    }
+    VNL_FOR(b, m.nbody) {
+      st3(L.xpos + 3 * b, ld3(src + 7 * b));
+      Q4 q = ld4(src + 7 * b + 3);
+      s[L.xquat + 4 * b] = q.w, s[L.xquat + 4 * b + 1] = q.x, s[L.xquat + 4 * b + 2] = q.y, s[L.xquat + 4 * b + 3] = q.z;
+    }
+    VNL_SYNC();
+    V3 O = ref_point();
+    VNL_FOR(j, m.njnt) {
+      int bd = m.jnt_body[j], da = m.jnt_dofadr[j];
+      if (m.jnt_type[j] == VNL_JNT_FREE) {
+        M3 R = qmat(ld4(L.xquat + 4 * bd));
+        V3 off = O - ld3(L.xpos + 3 * bd);
+        for (int t = 0; t < 3; t++) {
+          int o = L.cdof + 6 * (da + t);
+          s[o] = vreal(0.), s[o + 1] = vreal(0.), s[o + 2] = vreal(0.);
+          s[o + 3] = t == 0 ? vreal(1.) : vreal(0.), s[o + 4] = t == 1 ? vreal(1.) : vreal(0.),
+                s[o + 5] = t == 2 ? vreal(1.) : vreal(0.);
+        }
+        for (int t = 0; t < 3; t++) {
+          V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
+          st6(L.cdof + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
+        }
+      } else {
+        int p = parent_of(bd);
+        Q4 pq = ld4(L.xquat + 4 * p);
+        S6 la = ld6(L.cdof + 6 * da);
+        V3 axis = qrot(la.a, pq), anchor = ld3(L.xpos + 3 * p) + qrot(la.l, pq);
+        st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
       }
     }
     VNL_SYNC();
@@ -302,14 +366,12 @@ struct EnvWave {
   // Expects cinert in T1 (turned into crb in place).
   VNL_HD void mass_matrix(vreal diag_scale) const {
     tree_accumulate(L.T1, 10);
-    int F = L.T2 + 6 * m.nbody;  // per-dof crb * cdof
-    VNL_FOR(i, m.nv) st6(F + 6 * i, inert_mul(L.T1 + 10 * m.dof_body[i], ld6(L.cdof + 6 * i)));
-    VNL_SYNC();
-    VNL_FOR(k, m.nM) {
-      int i = m.M_row[k], j = m.M_anc[k];
-      vreal v = dot(ld6(F + 6 * i), ld6(L.cdof + 6 * j));
-      if (i == j) v += m.dof_armature[i] + diag_scale * m.dof_damping[i];
-      s[L.LD + k] = v;
+    VNL_FOR(i, m.nv) {
+      S6 f = inert_mul(L.T1 + 10 * m.dof_body[i], ld6(L.cdof + 6 * i));
+      int adr = madr(i), dep = eadr(i) - adr;
+      s[L.LD + adr] = dot(f, ld6(L.cdof + 6 * i)) + m.dof_armature[i] + diag_scale * m.dof_damping[i];
+#pragma unroll 2
+      for (int t = 1; t <= dep; t++) s[L.LD + adr + t] = dot(f, ld6(L.cdof + 6 * anc_of(adr + t)));
     }
     VNL_SYNC();
   }
@@ -327,7 +389,11 @@ struct EnvWave {
       if (dk == 0) continue;
       int np = dk * (dk + 1) / 2;
       VNL_FOR(p, np) {
-        int t = m.tri[p], a = t & 255, sidx = t >> 8;
+        // p = (sidx-1) sidx / 2 + (a-1), 1 <= a <= sidx <= dk
+        int sidx = (int)((sqrtf(8.f * (float)p + 1.f) + 1.f) * 0.5f);
+        while (sidx * (sidx - 1) / 2 > p) sidx--;
+        while (sidx * (sidx + 1) / 2 <= p) sidx++;
+        int a = p - sidx * (sidx - 1) / 2 + 1;
         vreal tmp = s[L.LD + adr_k + a] * inv;
         int dst = madr(anc_of(adr_k + a)) + sidx - a;
         s[L.LD + dst] -= tmp * s[L.LD + adr_k + sidx];
@@ -335,11 +401,44 @@ struct EnvWave {
       VNL_SYNC();
     }
     VNL_SYNC();
-    VNL_FOR(e2, m.nM) {
-      int i = m.M_row[e2];
-      if (anc_of(e2) != i) s[L.LD + e2] *= s[L.dinv + i];
+    VNL_FOR(i, m.nv) {
+      int adr = madr(i), dep = eadr(i) - adr;
+      vreal di = s[L.dinv + i];
+      for (int t = 1; t <= dep; t++) s[L.LD + adr + t] *= di;
     }
     VNL_SYNC();
+  }
+
+  // L -> L^-1 in place (same ancestor sparsity).  N(i,t) = -L(i,t) - sum_{u<t} L(i,u) N(anc_u, t-u):
+  // the rows of one depth level only need already-converted ancestor rows and their own (still L)
+  // row.  Per level: (A) stage the row base addresses of the ancestors, (B) all entries of the level
+  // in parallel into a staging buffer, (C) write back.
+  VNL_HD void invert_factor() const {
+    int stage = L.Ma;              // Ma|grad free while factorising
+    int* base = (int*)(s + L.Mgrad);  // Mgrad|search likewise
+    for (int lev = 1; lev <= m.max_depth; lev++) {
+      int q0 = lvl_start(lev), nrow = lvl_start(lev + 1) - q0, n = nrow * lev;
+      VNL_FOR(q, n) {
+        int i = lvl_dof(q0 + q / lev), t = q % lev + 1;
+        base[q] = madr(anc_of(madr(i) + t));
+      }
+      VNL_SYNC();
+      VNL_FOR(q, n) {
+        int rr = q / lev, i = lvl_dof(q0 + rr), t = q - rr * lev + 1;
+        int adr = madr(i);
+        const int* bb = base + rr * lev - 1;  // bb[u] = madr(anc_u(i))
+        vreal acc = -s[L.LD + adr + t];
+#pragma unroll 4
+        for (int u = 1; u < t; u++) acc -= s[L.LD + adr + u] * s[L.LD + bb[u] + t - u];
+        s[stage + q] = acc;
+      }
+      VNL_SYNC();
+      VNL_FOR(q, n) {
+        int rr = q / lev, i = lvl_dof(q0 + rr), t = q - rr * lev + 1;
+        s[L.LD + madr(i) + t] = s[stage + q];
+      }
+      VNL_SYNC();
+    }
   }
 
   // out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]   (A = strictly-lower part held in LD: L or L^-1)
@@ -347,6 +446,7 @@ struct EnvWave {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[in + i];
+#pragma unroll 4
       for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[in + anc_of(adr + t)];
       s[out + i] = scale_by_dinv ? acc * s[L.dinv + i] : acc;
     }
@@ -357,30 +457,11 @@ struct EnvWave {
     VNL_FOR(a, m.nv) {
       int da = eadr(a) - madr(a), nd = m.dof_ndesc[a];
       vreal acc = s[in + a];
+#pragma unroll 4
       for (int i = a + 1; i <= a + nd; i++) acc += s[L.LD + eadr(i) - da] * s[in + i];
       s[out + a] = dmode == 1 ? acc * s[L.dinv + a] : (dmode == 2 ? acc / s[L.dinv + a] : acc);
     }
     VNL_SYNC();
-  }
-
-  // L -> L^-1 in place (same ancestor sparsity).  N(i,t) = -L(i,t) - sum_{s<t} L(i,s) N(anc_s, t-s):
-  // rows of one depth level only need already-converted ancestor rows and their own (still L) row,
-  // so a level is computed into a staging buffer, then written back.
-  VNL_HD void invert_factor() const {
-    int stage = L.Ma;  // Ma|grad|Mgrad... are free while factorising
-    for (int lev = 1; lev <= m.max_depth; lev++) {
-      int p0 = m.lvl_ptr[lev], n = m.lvl_ptr[lev + 1] - p0;
-      VNL_FOR(q, n) {
-        int e2 = m.lvl_entry[p0 + q], i = m.M_row[e2];
-        int adr = madr(i), t = e2 - adr;
-        vreal acc = -s[L.LD + e2];
-        for (int u = 1; u < t; u++) acc -= s[L.LD + adr + u] * s[L.LD + madr(anc_of(adr + u)) + t - u];
-        s[stage + q] = acc;
-      }
-      VNL_SYNC();
-      VNL_FOR(q, n) s[L.LD + m.lvl_entry[p0 + q]] = s[stage + q];
-      VNL_SYNC();
-    }
   }
 
   // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
@@ -394,6 +475,7 @@ struct EnvWave {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[vec + i];
+#pragma unroll 4
       for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[vec + anc_of(adr + t)];
       s[L.tmp2 + i] = acc / s[L.dinv + i];
     }
@@ -402,15 +484,25 @@ struct EnvWave {
   }
 
   // ------------------------------------------------------------------ velocity
-  // com_vel + rne: qfrc_bias -> L.bias.  cvel stays in T2[0 .. 6 nbody) for make_constraint.
-  VNL_HD void bias_forces() const {
-    int cv = L.T2, ca = L.T2 + 6 * m.nbody, cf = L.Jaref;
-    VNL_SERIAL {
-      st6(cv, S6{v3(0, 0, 0), v3(0, 0, 0)});
-      st6(ca, S6{v3(0, 0, 0), v3(-m.gx, -m.gy, -m.gz)});
-      for (int b = 1; b < m.nbody; b++) {
-        int p = m.body_parent[b];
-        S6 vel = ld6(cv + 6 * p), acc = ld6(ca + 6 * p);
+  // com_vel + rne: qfrc_bias -> L.bias.  Body velocities / accelerations are tree prefixes
+  // (pointer jumping) of per-body contributions; returns the LDS offset of cvel (kept for
+  // make_constraint).  Needs cinert in T1.
+  VNL_HD int bias_forces() const {
+    int nb6 = 6 * m.nbody;
+    VNL_FOR(i, nb6) {
+      int b = i / 6, k = i - 6 * b;
+      int da = dofadr_of(b), nd = dofnum_of(b);
+      vreal v = vreal(0.);
+      for (int t = 0; t < nd; t++) v += s[L.cdof + 6 * (da + t) + k] * s[L.qvel + da + t];
+      s[L.T2 + i] = v;
+    }
+    VNL_SYNC();
+    int cv = tree_prefix(L.T2, L.T2 + nb6);
+    int E0 = L.efc_D, E1 = L.efc_D + nb6;
+    VNL_FOR(b, m.nbody) {  // own acceleration term: sum over the body's dofs of cdof_dot * qvel
+      S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
+      if (b > 0) {
+        S6 vel = ld6(cv + 6 * parent_of(b));
         int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
         for (int k = 0; k < jn; k++) {
           int j = ja + k, da = m.jnt_dofadr[j];
@@ -430,22 +522,26 @@ struct EnvWave {
             vel = vel + c * qd;
           }
         }
-        st6(cv + 6 * b, vel), st6(ca + 6 * b, acc);
       }
+      st6(E0 + 6 * b, acc);
     }
     VNL_SYNC();
+    int ca = tree_prefix(E0, E1);
+    int cf = ca == E0 ? E1 : E0;
     VNL_FOR(b, m.nbody) {
       if (b == 0) {
         st6(cf, S6{v3(0, 0, 0), v3(0, 0, 0)});
         continue;
       }
-      S6 vel = ld6(cv + 6 * b);
-      st6(cf + 6 * b, inert_mul(L.T1 + 10 * b, ld6(ca + 6 * b)) + mcross_force(vel, inert_mul(L.T1 + 10 * b, vel)));
+      S6 vel = ld6(cv + 6 * b), acc = ld6(ca + 6 * b);
+      acc.l = acc.l + v3(-m.gx, -m.gy, -m.gz);  // cacc of the world body, inherited by every body
+      st6(cf + 6 * b, inert_mul(L.T1 + 10 * b, acc) + mcross_force(vel, inert_mul(L.T1 + 10 * b, vel)));
     }
     VNL_SYNC();
     tree_accumulate(cf, 6);
     VNL_FOR(d, m.nv) s[L.bias + d] = dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
     VNL_SYNC();
+    return cv;
   }
 
   // passive + actuation + qfrc_smooth + qacc_smooth
@@ -510,7 +606,7 @@ struct EnvWave {
   // collision (plane vs sphere / capsule / ellipsoid) + constraint rows, one lane per limit row /
   // per geom.  Rows that MJX would mask out (pos >= 0) get D = 0: they add nothing to cost, force
   // or gradient.  Needs cvel (T2) from bias_forces for aref.
-  VNL_HD void make_constraint() const {
+  VNL_HD void make_constraint(int cvel) const {
     V3 O = ref_point();
     V3 n = v3(m.pnx, m.pny, m.pnz), pp = v3(m.ppx, m.ppy, m.ppz);
     VNL_FOR(r, m.nlimit) {
@@ -563,7 +659,7 @@ struct EnvWave {
       }
       V3 t2 = cross(n, t1);
       vreal mu = m.cg_mu[g], margin = m.cg_margin[g], invw = m.cg_invweight[g];
-      S6 vel = ld6(L.T2 + 6 * bd);
+      S6 vel = ld6(cvel + 6 * bd);
       for (int q = 0; q < nc; q++) {
         int c = c0 + q, r0 = m.nlimit + 4 * c;
         vreal dist = q == 0 ? dist0 : dist1;
@@ -594,26 +690,6 @@ struct EnvWave {
     }
     VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
     VNL_SYNC();
-  }
-
-  // Tree prefix by pointer jumping: on entry buf0[6b+k] holds each body's own contribution; on exit
-  // the returned buffer holds the sum over the body's whole ancestor path.  jump_r[b] = 2^r-th
-  // ancestor (0 = none), log2(depth) rounds, ping-pong between buf0 and buf1.
-  VNL_HD int tree_prefix(int buf0, int buf1) const {
-    int src = buf0, dst = buf1;
-    for (int r = 0; r < m.jump_rounds; r++) {
-      const unsigned char* jr = m.jump + r * m.nbody;
-      VNL_FOR(i, 6 * m.nbody) {
-        int b = i / 6, j = jr[b];
-        vreal v = s[src + i];
-        if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
-        s[dst + i] = v;
-      }
-      VNL_SYNC();
-      int t = src;
-      src = dst, dst = t;
-    }
-    return src;
   }
 
   // body twists V[b] = sum_{d in path(b)} cdof[d] * vec[d]; returns the LDS offset of V (inside T2)
@@ -880,7 +956,7 @@ struct EnvWave {
     kinematics();
     VNL_PROF(0);
     body_inertias(true);
-    bias_forces();
+    int cvel = bias_forces();
     VNL_PROF(3);
     mass_matrix(vreal(0.));
     VNL_PROF(1);
@@ -890,7 +966,7 @@ struct EnvWave {
     VNL_PROF(2);
     smooth_forces();
     VNL_PROF(4);
-    make_constraint();
+    make_constraint(cvel);
     VNL_PROF(5);
     solve();
   }

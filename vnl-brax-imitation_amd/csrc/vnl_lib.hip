@@ -146,7 +146,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
                {"body_rootid", (size_t)nb, true}, {"body_dofadr", (size_t)nb, true}, {"body_dofnum", (size_t)nb, true}, {"body_pos", 3u * nb, false}, {"body_quat", 4u * nb, false},
                {"body_ipos", 3u * nb, false}, {"body_inertia_full", 9u * nb, false}, {"body_mass", (size_t)nb, false},
                {"body_invweight0", 2u * nb, false}, {"jnt_type", (size_t)nj, true}, {"jnt_qposadr", (size_t)nj, true},
-               {"jnt_dofadr", (size_t)nj, true}, {"jnt_limited", (size_t)nj, true}, {"jnt_pos", 3u * nj, false},
+               {"jnt_dofadr", (size_t)nj, true}, {"jnt_bodyid", (size_t)nj, true}, {"jnt_limited", (size_t)nj, true}, {"jnt_pos", 3u * nj, false},
                {"jnt_axis", 3u * nj, false}, {"jnt_range", 2u * nj, false}, {"jnt_stiffness", (size_t)nj, false},
                {"jnt_margin", (size_t)nj, false}, {"jnt_solref", 2u * nj, false}, {"jnt_solimp", 5u * nj, false},
                {"qpos0", (size_t)d.nq, false}, {"qpos_spring", (size_t)d.nq, false}, {"dof_bodyid", (size_t)nv, true},
@@ -244,7 +244,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     }
     UPF(body_inertia6, i6)
   }
-  UPI(jnt_type, jt) UPI(jnt_qposadr, I("jnt_qposadr")) UPI(jnt_dofadr, I("jnt_dofadr"))
+  UPI(jnt_type, jt) UPI(jnt_qposadr, I("jnt_qposadr")) UPI(jnt_dofadr, I("jnt_dofadr")) UPI(jnt_body, I("jnt_bodyid"))
   UPF(jnt_pos, F("jnt_pos")) UPF(jnt_axis, F("jnt_axis")) UPF(jnt_stiffness, F("jnt_stiffness"))
   {
     std::vector<double> q0(nj), qs(nj);
@@ -293,21 +293,22 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     for (int i = 0; i < nv; i++) maxd = depth[i] > maxd ? depth[i] : maxd;
     d.max_depth = maxd;
     if (nv > 255 || nb > 255 || maxd > 254) return fail(VNL_ERR_UNSUPPORTED, "model too large for 8-bit index tables");
-    std::vector<int> tri;  // pairs (a, sidx = a + c), ordered by sidx then a: a prefix enumerates any depth
-    for (int sidx = 1; sidx <= maxd; sidx++)
-      for (int a = 1; a <= sidx; a++) tri.push_back(a | (sidx << 8));
-    std::vector<int> lvl_ptr(maxd + 2, 0), lvl_entry;
-    int max_level = 0;
+    std::vector<unsigned char> lvl_tab;  // dofs sorted by depth, then the level start offsets
+    std::vector<int> lvl_start(maxd + 2, 0);
     for (int lev = 0; lev <= maxd; lev++) {
-      lvl_ptr[lev] = (int)lvl_entry.size();
+      lvl_start[lev] = (int)lvl_tab.size();
+      int cnt = 0;
       for (int i = 0; i < nv; i++)
-        if (depth[i] == lev)
-          for (int t = 1; t <= depth[i]; t++) lvl_entry.push_back(madr[i] + t);
-      int cnt = (int)lvl_entry.size() - lvl_ptr[lev];
-      max_level = cnt > max_level ? cnt : max_level;
+        if (depth[i] == lev) lvl_tab.push_back((unsigned char)i), cnt++;
+      if (cnt * lev > 2 * nv) return fail(VNL_ERR_UNSUPPORTED, "tree level too wide for the inversion staging buffer");
     }
-    lvl_ptr[maxd + 1] = (int)lvl_entry.size();
-    if (max_level > 3 * nv) return fail(VNL_ERR_UNSUPPORTED, "tree level too wide for the inversion staging buffer");
+    lvl_start[maxd + 1] = (int)lvl_tab.size();
+    for (int v : lvl_start) lvl_tab.push_back((unsigned char)v);
+    {
+      const unsigned char* dp = nullptr;
+      if ((rc = upload<unsigned char, unsigned char>(env, lvl_tab, &dp)) != VNL_OK) return rc;
+      d.lvl_tab = dp;
+    }
     std::vector<int> limrow(nv, -1);
     {
       int r = 0;
@@ -315,7 +316,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         if (I("jnt_limited")[j] && jt[j] == VNL_JNT_HINGE) limrow[I("jnt_dofadr")[j]] = r++;
     }
     UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc) UPI(M_row, row)
-    UPI(dof_ndesc, ndesc) UPI(tri, tri) UPI(lvl_ptr, lvl_ptr) UPI(lvl_entry, lvl_entry) UPI(dof_limrow, limrow)
+    UPI(dof_ndesc, ndesc) UPI(dof_limrow, limrow)
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
@@ -378,6 +379,7 @@ static void layout(vnl_env* env) {
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
   L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
   L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + d.ncon));
+  L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
   L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));
   L.total = (o + 3) & ~3;
 }

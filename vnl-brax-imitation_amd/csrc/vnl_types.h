@@ -30,7 +30,7 @@ struct DevModel {
   const unsigned char* jump; /* [jump_rounds][nbody]: 2^r-th ancestor body, 0 = none */
   const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
   // joints
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_body;
   const vreal *jnt_pos, *jnt_axis, *jnt_qpos0, *jnt_stiffness, *jnt_springref;
   // limit rows (one per limited hinge)
   const int *lim_qadr, *lim_dof;
@@ -39,8 +39,7 @@ struct DevModel {
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
-  const int *tri;                    /* universal (a | (a+c) << 8) enumeration of factor update pairs */
-  const int *lvl_ptr, *lvl_entry;    /* strictly-lower entries grouped by depth of their row dof */
+  const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
   const vreal *dof_armature, *dof_damping;
   // actuators
   const int *act_dof, *act_limited;
@@ -73,6 +72,7 @@ struct WsLayout {
   int T2;  /* 12*nbody: cvel | cacc (-> per-dof crb*cdof) ; in the solver: twists V | wrenches W */
   int bias, smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2, qfrc_act;
   int tab_anc, tab_madr, tab_E, tab_body; /* index tables (bytes / ints) staged in LDS */
+  int tab_lvl;                            /* nv + max_depth + 2 bytes */
   int act_list;                           /* ncon bytes: contacts with D != 0, then their count (int) */
   int con_dist, con_r, con_t1;
   int lim_sign;
