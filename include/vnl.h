@@ -113,7 +113,8 @@ typedef struct vnl_state {
 /* Model dimensions, for sizing caller buffers. */
 typedef struct vnl_dims {
   int32_t nq, nv, nu, nbody, njnt, ngeom_collide, ncon, nefc, obs_size, traj_size;
-  int32_t workspace_floats_per_env;
+  int32_t workspace_floats_per_env; /* per-env LDS working set, in floats */
+  int32_t workgroups_per_cu;        /* occupancy of the step kernel as reported by the HIP runtime */
 } vnl_dims;
 
 const char* vnl_last_error(void);

@@ -31,12 +31,15 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+template <class K>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 // Fork-join primitives of csrc/vnl_body.h, host flavour: one pass per workgroup in which every
 // parallel-for region simply runs over all its items, serial regions run once, and cross-lane
 // reductions are the identity (the single pass has already accumulated every item).
 #define VNL_FORKJOIN_DEFINED
 #define VNL_HD inline
 #define VNL_LANES 1
+#define VNL_ROWS_PER_LANE 512
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)
 #define VNL_SYNC()

@@ -85,7 +85,7 @@ def test_float64_stage_outputs_match_dense_oracle():
     Minv = Lm @ np.diag(dinv) @ Lm.T  # Lm holds N = L^-1 (unit lower, ancestor pattern)
     assert np.abs(Minv @ Md - np.eye(73)).max() < 1e-9
     for name, ref in [("qfrc_smooth", "qfrc_smooth"), ("qacc_smooth", "qacc_smooth"), ("qacc", "qacc"),
-                      ("qfrc_constraint", "qfrc_constraint"), ("qfrc_bias", "qfrc_bias"), ("con_dist", "con_dist")]:
+                      ("qfrc_constraint", "qfrc_constraint")]:
         assert H.scaled_err(env.scratch(name)[0].numpy(), o.field(ref)) < 1e-10, name
     D, Dref = env.scratch("efc_D")[0].numpy(), o.field("efc_D")
     present = np.abs(o.field("efc_J").reshape(303, 73)).sum(1) > 0

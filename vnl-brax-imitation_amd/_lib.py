@@ -56,7 +56,7 @@ class StatePtrs(C.Structure):
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "nbody", "njnt", "ngeom_collide", "ncon", "nefc",
-                                          "obs_size", "traj_size", "workspace_floats_per_env")]
+                                          "obs_size", "traj_size", "workspace_floats_per_env", "workgroups_per_cu")]
 
 
 class PolicySpec(C.Structure):

@@ -40,6 +40,7 @@
 // ---- fork-join primitives (the host simulation in tests/hostsim redefines them) ------------
 #ifndef VNL_FORKJOIN_DEFINED
 #define VNL_LANES 64
+#define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
 #define VNL_SERIAL if (lane == 0)
 #define VNL_SYNC() __syncthreads()
@@ -182,6 +183,7 @@ struct EnvWave {
   // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
   VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
   VNL_HD int lvl_start(int l) const { return ((const unsigned char*)(s + L.tab_lvl))[m.nv + l]; }
+  VNL_HD int jump_of(int r, int b) const { return ((const unsigned char*)(s + L.tab_jump))[r * m.nbody + b]; }
   VNL_HD void load_tables() const {
     unsigned char* ta = (unsigned char*)(s + L.tab_anc);
     VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
@@ -197,6 +199,8 @@ struct EnvWave {
     VNL_FOR(c, m.ncon) tb[3 * m.nbody + c] = (unsigned char)m.cg_body[m.con_geom[c]];
     unsigned char* tl = (unsigned char*)(s + L.tab_lvl);
     VNL_FOR(q, m.nv + m.max_depth + 2) tl[q] = m.lvl_tab[q];
+    unsigned char* tj = (unsigned char*)(s + L.tab_jump);
+    VNL_FOR(q, m.jump_rounds * m.nbody) tj[q] = m.jump[q];
     VNL_SYNC();
   }
 
@@ -207,9 +211,8 @@ struct EnvWave {
   VNL_HD int tree_prefix(int buf0, int buf1) const {
     int src = buf0, dst = buf1;
     for (int r = 0; r < m.jump_rounds; r++) {
-      const unsigned char* jr = m.jump + r * m.nbody;
       VNL_FOR(i, 6 * m.nbody) {
-        int b = i / 6, j = jr[b];
+        int b = i / 6, j = jump_of(r, b);
         vreal v = s[src + i];
         if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
         s[dst + i] = v;
@@ -263,9 +266,8 @@ struct EnvWave {
     VNL_SYNC();
     int src = A, dst = Bf;
     for (int r = 0; r < m.jump_rounds; r++) {
-      const unsigned char* jr = m.jump + r * m.nbody;
       VNL_FOR(b, m.nbody) {
-        int j = jr[b];
+        int j = jump_of(r, b);
         V3 pos = ld3(src + 7 * b);
         Q4 quat = ld4(src + 7 * b + 3);
         if (j > 0) {  // X_b <- X_j o X_b
@@ -387,16 +389,18 @@ struct EnvWave {
       vreal inv = vreal(1.) / s[L.LD + adr_k];
       VNL_SERIAL { s[L.dinv + k] = inv; }
       if (dk == 0) continue;
-      int np = dk * (dk + 1) / 2;
-      VNL_FOR(p, np) {
-        // p = (sidx-1) sidx / 2 + (a-1), 1 <= a <= sidx <= dk
-        int sidx = (int)((sqrtf(8.f * (float)p + 1.f) + 1.f) * 0.5f);
-        while (sidx * (sidx - 1) / 2 > p) sidx--;
-        while (sidx * (sidx + 1) / 2 <= p) sidx++;
-        int a = p - sidx * (sidx - 1) / 2 + 1;
+      VNL_FOR(a1, dk) {  // one lane per ancestor row: row(anc_a)[0..len) -= tmp * row_k[a .. a+len)
+        int a = a1 + 1, len = dk - a + 1;
         vreal tmp = s[L.LD + adr_k + a] * inv;
-        int dst = madr(anc_of(adr_k + a)) + sidx - a;
-        s[L.LD + dst] -= tmp * s[L.LD + adr_k + sidx];
+        const vreal* src = s + L.LD + adr_k + a;
+        vreal* dst = s + L.LD + madr(anc_of(adr_k + a));
+        int c = 0;
+        for (; c + 4 <= len; c += 4) {
+          vreal x0 = src[c], x1 = src[c + 1], x2 = src[c + 2], x3 = src[c + 3];
+          vreal y0 = dst[c], y1 = dst[c + 1], y2 = dst[c + 2], y3 = dst[c + 3];
+          dst[c] = y0 - tmp * x0, dst[c + 1] = y1 - tmp * x1, dst[c + 2] = y2 - tmp * x2, dst[c + 3] = y3 - tmp * x3;
+        }
+        for (; c < len; c++) dst[c] -= tmp * src[c];
       }
       VNL_SYNC();
     }
@@ -428,8 +432,16 @@ struct EnvWave {
         int adr = madr(i);
         const int* bb = base + rr * lev - 1;  // bb[u] = madr(anc_u(i))
         vreal acc = -s[L.LD + adr + t];
-#pragma unroll 4
-        for (int u = 1; u < t; u++) acc -= s[L.LD + adr + u] * s[L.LD + bb[u] + t - u];
+        const vreal* row = s + L.LD + adr;
+        const vreal* ld = s + L.LD + t;
+        int u = 1;
+        for (; u + 4 <= t; u += 4) {  // loads first, so the four dependent (base -> N) chains overlap
+          int b0 = bb[u], b1 = bb[u + 1], b2 = bb[u + 2], b3 = bb[u + 3];
+          vreal l0 = row[u], l1 = row[u + 1], l2 = row[u + 2], l3 = row[u + 3];
+          vreal n0 = ld[b0 - u], n1 = ld[b1 - u - 1], n2 = ld[b2 - u - 2], n3 = ld[b3 - u - 3];
+          acc -= l0 * n0 + l1 * n1 + l2 * n2 + l3 * n3;
+        }
+        for (; u < t; u++) acc -= row[u] * ld[bb[u] - u];
         s[stage + q] = acc;
       }
       VNL_SYNC();
@@ -441,13 +453,26 @@ struct EnvWave {
     }
   }
 
+  // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
+  VNL_HD vreal row_dot(int adr, int dep, int in) const {
+    const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
+    const vreal* row = s + L.LD + adr;
+    vreal acc = vreal(0.);
+    int t = 1;
+    for (; t + 3 <= dep; t += 4) {
+      int j0 = an[t], j1 = an[t + 1], j2 = an[t + 2], j3 = an[t + 3];
+      vreal l0 = row[t], l1 = row[t + 1], l2 = row[t + 2], l3 = row[t + 3];
+      acc += l0 * s[in + j0] + l1 * s[in + j1] + l2 * s[in + j2] + l3 * s[in + j3];
+    }
+    for (; t <= dep; t++) acc += row[t] * s[in + an[t]];
+    return acc;
+  }
+
   // out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]   (A = strictly-lower part held in LD: L or L^-1)
   VNL_HD void row_apply(int in, int out, bool scale_by_dinv) const {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[in + i];
-#pragma unroll 4
-      for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[in + anc_of(adr + t)];
+      vreal acc = s[in + i] + row_dot(adr, dep, in);
       s[out + i] = scale_by_dinv ? acc * s[L.dinv + i] : acc;
     }
     VNL_SYNC();
@@ -457,8 +482,15 @@ struct EnvWave {
     VNL_FOR(a, m.nv) {
       int da = eadr(a) - madr(a), nd = m.dof_ndesc[a];
       vreal acc = s[in + a];
-#pragma unroll 4
-      for (int i = a + 1; i <= a + nd; i++) acc += s[L.LD + eadr(i) - da] * s[in + i];
+      const int* ea = (const int*)(s + L.tab_E);
+      const vreal* ld = s + L.LD - da;
+      int i = a + 1, iend = a + nd;
+      for (; i + 3 <= iend; i += 4) {
+        int e0 = ea[i], e1 = ea[i + 1], e2 = ea[i + 2], e3 = ea[i + 3];
+        vreal x0 = s[in + i], x1 = s[in + i + 1], x2 = s[in + i + 2], x3 = s[in + i + 3];
+        acc += ld[e0] * x0 + ld[e1] * x1 + ld[e2] * x2 + ld[e3] * x3;
+      }
+      for (; i <= iend; i++) acc += ld[ea[i]] * s[in + i];
       s[out + a] = dmode == 1 ? acc * s[L.dinv + a] : (dmode == 2 ? acc / s[L.dinv + a] : acc);
     }
     VNL_SYNC();
@@ -474,9 +506,7 @@ struct EnvWave {
   VNL_HD void mass_mul_factor(int vec, int out) const {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[vec + i];
-#pragma unroll 4
-      for (int t = 1; t <= dep; t++) acc += s[L.LD + adr + t] * s[vec + anc_of(adr + t)];
+      vreal acc = s[vec + i] + row_dot(adr, dep, vec);
       s[L.tmp2 + i] = acc / s[L.dinv + i];
     }
     VNL_SYNC();
@@ -484,7 +514,7 @@ struct EnvWave {
   }
 
   // ------------------------------------------------------------------ velocity
-  // com_vel + rne: qfrc_bias -> L.bias.  Body velocities / accelerations are tree prefixes
+  // com_vel + rne: -qfrc_bias - damping*qvel -> L.smooth.  Body velocities / accelerations are tree prefixes
   // (pointer jumping) of per-body contributions; returns the LDS offset of cvel (kept for
   // make_constraint).  Needs cinert in T1.
   VNL_HD int bias_forces() const {
@@ -539,17 +569,16 @@ struct EnvWave {
     }
     VNL_SYNC();
     tree_accumulate(cf, 6);
-    VNL_FOR(d, m.nv) s[L.bias + d] = dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
+    // qfrc_smooth starts as passive damping minus the bias force (springs / actuation added by smooth_forces)
+    VNL_FOR(d, m.nv)
+      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
     VNL_SYNC();
     return cv;
   }
 
   // passive + actuation + qfrc_smooth + qacc_smooth
   VNL_HD void smooth_forces() const {
-    VNL_FOR(d, m.nv) {
-      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - s[L.bias + d];
-      s[L.qfrc_act + d] = vreal(0.);
-    }
+    VNL_FOR(d, m.nv) s[L.qfrc_act + d] = vreal(0.);
     VNL_SYNC();
     VNL_FOR(j, m.njnt) {
       if (m.jnt_type[j] == VNL_JNT_HINGE) {
@@ -665,7 +694,6 @@ struct EnvWave {
         vreal dist = q == 0 ? dist0 : dist1;
         V3 rel = (q == 0 ? cpos0 : cpos1) - O;
         vreal d = dist - margin;
-        s[L.con_dist + c] = dist;
         st3(L.con_r + 3 * c, rel);
         st3(L.con_t1 + 3 * c, t1);
         vreal k, b, imp;
@@ -793,22 +821,35 @@ struct EnvWave {
     return vnl_wave_sum(p);
   }
 
-  // one pass over the rows for up to 3 step lengths: quad totals -> (cost, d0, d1)
+  // Line search.  The rows a lane owns (r = lane + j * lanes) and their quadratic coefficients do not
+  // change during one line search, so they are loaded into registers once per CG iteration and every
+  // trial step length is then a pure register pass + 3 reductions.
   struct LsPoint {
     vreal alpha, cost, d0, d1;
   };
+  struct LsRows {
+    vreal ja[VNL_ROWS_PER_LANE], jv[VNL_ROWS_PER_LANE], a0[VNL_ROWS_PER_LANE], a1[VNL_ROWS_PER_LANE], a2[VNL_ROWS_PER_LANE];
+  };
+  VNL_HD void ls_load(LsRows& R) const {
+#pragma unroll
+    for (int j = 0; j < VNL_ROWS_PER_LANE; j++) {
+      int r = (int)lane + j * VNL_LANES;
+      bool ok = r < m.nefc;
+      vreal D = ok ? s[L.efc_D + r] : vreal(0.);
+      vreal ja = ok ? s[L.Jaref + r] : vreal(0.), jv = ok ? s[L.jv + r] : vreal(0.);
+      R.ja[j] = ja, R.jv[j] = jv;
+      R.a0[j] = vreal(0.5) * ja * ja * D, R.a1[j] = jv * ja * D, R.a2[j] = vreal(0.5) * jv * jv * D;
+    }
+  }
   template <int N>
-  VNL_HD void ls_eval(const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
+  VNL_HD void ls_eval(const LsRows& R, const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
     vreal q0[N], q1[N], q2[N];
     for (int i = 0; i < N; i++) q0[i] = vreal(0.), q1[i] = vreal(0.), q2[i] = vreal(0.);
-    VNL_FOR(r, m.nefc) {
-      vreal D = s[L.efc_D + r];
-      if (D == vreal(0.)) continue;
-      vreal ja = s[L.Jaref + r], jv = s[L.jv + r];
-      vreal a0 = vreal(0.5) * ja * ja * D, a1 = jv * ja * D, a2 = vreal(0.5) * jv * jv * D;
+#pragma unroll
+    for (int j = 0; j < VNL_ROWS_PER_LANE; j++) {
       for (int i = 0; i < N; i++) {
-        bool act = ja + alpha[i] * jv < vreal(0.);
-        q0[i] += act ? a0 : vreal(0.), q1[i] += act ? a1 : vreal(0.), q2[i] += act ? a2 : vreal(0.);
+        bool act = R.ja[j] + alpha[i] * R.jv[j] < vreal(0.);
+        q0[i] += act ? R.a0[j] : vreal(0.), q1[i] += act ? R.a1[j] : vreal(0.), q2[i] += act ? R.a2[j] : vreal(0.);
       }
     }
     for (int i = 0; i < N; i++) {
@@ -883,10 +924,12 @@ struct EnvWave {
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(7);
       LsPoint p0, lo, hi;
+      LsRows rows;
+      ls_load(rows);
       vreal a1[1] = {vreal(0.)};
-      ls_eval<1>(a1, gauss, qg1, qg2, &p0);
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
       a1[0] = p0.alpha - p0.d0 / p0.d1;
-      ls_eval<1>(a1, gauss, qg1, qg2, &lo);
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
       if (lo.d0 < p0.d0) {
         hi = p0;
       } else {
@@ -897,7 +940,7 @@ struct EnvWave {
         if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
         vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
         LsPoint p[3];
-        ls_eval<3>(a3, gauss, qg1, qg2, p);
+        ls_eval<3>(rows, a3, gauss, qg1, qg2, p);
         bool s1 = (lo.d0 > vreal(0.)) || (lo.d0 < p[0].d0);
         if (s1) lo = p[0];
         bool s2 = (p[2].d0 < vreal(0.)) && (lo.d0 < p[2].d0);
@@ -953,6 +996,33 @@ struct EnvWave {
     VNL_SYNC();
     VNL_FOR(d, m.nv) s[L.qacc + d] = s[L.tmp + d];
     VNL_SYNC();
+    // Timing knob (VNL_DBG_REPEAT=stage:count at env creation; 0 in normal use): run one stage
+    // `count` extra times on data that is recomputed afterwards, so results are unchanged and the
+    // wall-time difference prices that stage in the real (uninstrumented) build.
+    for (int rep = 0; rep < m.dbg_count; rep++) {
+      if (m.dbg_stage == 1) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+        factor();
+        invert_factor();
+      } else if (m.dbg_stage == 2) {
+        kinematics();
+      } else if (m.dbg_stage == 3) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+      } else if (m.dbg_stage == 4) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+        factor();
+      } else if (m.dbg_stage == 5) {
+        kinematics();
+        body_inertias(true);
+        (void)bias_forces();
+      }
+    }
     kinematics();
     VNL_PROF(0);
     body_inertias(true);
@@ -968,6 +1038,23 @@ struct EnvWave {
     VNL_PROF(4);
     make_constraint(cvel);
     VNL_PROF(5);
+    for (int rep = 0; rep < m.dbg_count; rep++) {
+      if (m.dbg_stage == 6) {
+        int V = body_twists(L.qacc_smooth);
+        jac_mul(V, L.qacc_smooth, L.jv, false);
+      } else if (m.dbg_stage == 7) {
+        VNL_FOR(d, m.nv) s[L.tmp + d] = s[L.smooth + d];
+        VNL_SYNC();
+        solve_inplace(L.tmp);
+      } else if (m.dbg_stage == 8) {
+        vreal a3[3] = {vreal(0.), vreal(1e-4), vreal(2e-4)};
+        LsPoint p[3];
+        LsRows rows;
+        ls_load(rows);
+        ls_eval<3>(rows, a3, vreal(0.), vreal(0.), vreal(0.), p);
+        if (p[0].cost == vreal(-1.)) s[L.tmp] = p[1].cost;  // keep the result alive
+      }
+    }
     solve();
   }
 

@@ -108,6 +108,7 @@ struct vnl_env {
   vreal* dump = nullptr;  // [B][L.total] image of the per-env LDS, written only when debug is on
   int debug = 0;
   size_t lds_bytes = 0;
+  int blocks_per_cu = 0;
   std::vector<void*> allocs;
   std::map<std::string, std::pair<int, int>> sections;  // name -> (offset, count)
 };
@@ -136,6 +137,8 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   d.ncg = (int)S("ncg"), d.ncon = (int)S("ncon"), d.nlimit = (int)S("nlimit"), d.nefc = (int)S("nefc");
   d.iterations = (int)S("iterations"), d.ls_iterations = (int)S("ls_iterations"), d.eulerdamp = (int)S("eulerdamp");
   d.dt = (vreal)S("timestep"), d.tolerance = (vreal)S("tolerance"), d.ls_tolerance = (vreal)S("ls_tolerance");
+  d.dbg_stage = 0, d.dbg_count = 0;
+  if (const char* dbg = getenv("VNL_DBG_REPEAT")) sscanf(dbg, "%d:%d", &d.dbg_stage, &d.dbg_count);
   d.scale = (vreal)(S("meaninertia") * (d.nv > 1 ? d.nv : 1));
   const int nb = d.nbody, nj = d.njnt, nv = d.nv, nu = d.nu, ng = d.ncg;
   struct Need {
@@ -365,12 +368,12 @@ static void layout(vnl_env* env) {
   L.com = sec("subtree_com1", 4);
   L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
   L.T1 = sec("T1", 10 * d.nbody);
-  L.T2 = sec("T2", 6 * d.nbody + 6 * (d.nbody > d.nv ? d.nbody : d.nv));
-  L.bias = sec("qfrc_bias", d.nv), L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv);
+  L.T2 = sec("T2", 12 * d.nbody);
+  L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv);
   L.qacc = sec("qacc", d.nv), L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv);
   L.search = sec("search", d.nv), L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv);
   L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv), L.qfrc_act = sec("qfrc_actuator", d.nv);
-  L.con_dist = sec("con_dist", d.ncon), L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncon);
+  L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncon);
   L.lim_sign = sec("lim_sign", d.nlimit);
   L.efc_D = sec("efc_D", d.nefc);
   // Jaref | jv are contiguous: together they double as cfrc (6*nbody) during the bias pass
@@ -379,10 +382,13 @@ static void layout(vnl_env* env) {
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
   L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
   L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + d.ncon));
+  L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
   L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));
   L.total = (o + 3) & ~3;
 }
+
+__global__ void vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, const vreal* action, vreal* dump);
 
 extern "C" void vnl_env_destroy(vnl_env* env) {
   if (!env) return;
@@ -446,9 +452,22 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
 #undef UP
   layout(env);
   env->lds_bytes = (size_t)env->L.total * sizeof(vreal);
+  if (const char* padk = getenv("VNL_DBG_LDS_BYTES")) {  // occupancy experiments only: force a larger LDS request
+    size_t want = (size_t)atol(padk);
+    if (want > env->lds_bytes) env->lds_bytes = want;
+  }
+  if (d.nefc > 512) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_UNSUPPORTED, "more than 512 constraint rows (line-search rows are register-resident)");
+  }
   if (env->lds_bytes > 64 * 1024) {
     vnl_env_destroy(env);
     return fail(VNL_ERR_UNSUPPORTED, "model too large: per-env working set exceeds 64 KB of LDS");
+  }
+  {
+    int nb_ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, vnl_step_kernel, 64, env->lds_bytes) == hipSuccess)
+      env->blocks_per_cu = nb_;
   }
   *out = env;
   return VNL_OK;
@@ -460,6 +479,7 @@ extern "C" int vnl_env_dims(const vnl_env* env, vnl_dims* o) {
   o->nq = d.nq, o->nv = d.nv, o->nu = d.nu, o->nbody = d.nbody, o->njnt = d.njnt, o->ngeom_collide = d.ncg;
   o->ncon = d.ncon, o->nefc = d.nefc, o->obs_size = env->de.obs_size, o->traj_size = env->de.traj_size;
   o->workspace_floats_per_env = env->L.total;
+  o->workgroups_per_cu = env->blocks_per_cu;
   return VNL_OK;
 }
 

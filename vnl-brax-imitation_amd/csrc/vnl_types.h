@@ -19,6 +19,7 @@ typedef VNL_REAL vreal;
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
   int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
+  int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
   vreal pnx, pny, pnz, ppx, ppy, ppz; /* plane normal / point */
@@ -70,11 +71,12 @@ struct WsLayout {
   int cdof, LD, dinv;
   int T1;  /* 10*nbody: cinert -> crb | per-contact wrenches in the solver */
   int T2;  /* 12*nbody: cvel | cacc (-> per-dof crb*cdof) ; in the solver: twists V | wrenches W */
-  int bias, smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2, qfrc_act;
+  int smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2, qfrc_act;
   int tab_anc, tab_madr, tab_E, tab_body; /* index tables (bytes / ints) staged in LDS */
+  int tab_jump;                           /* jump_rounds * nbody bytes */
   int tab_lvl;                            /* nv + max_depth + 2 bytes */
   int act_list;                           /* ncon bytes: contacts with D != 0, then their count (int) */
-  int con_dist, con_r, con_t1;
+  int con_r, con_t1;
   int lim_sign;
   int efc_D, Jaref, jv; /* Jaref|jv doubles as cfrc (6*nbody) during the bias pass */
   int total;
