@@ -40,12 +40,17 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_HD inline
 #define VNL_LANES 1
 #define VNL_ROWS_PER_LANE 512
+#define VNL_ROWS_SMALL 320
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)
 #define VNL_SYNC()
 #define VNL_LDS_DECL(name) static thread_local vreal name[32768]
 #define vnl_wave_sum(x) (x)
 #define vnl_wave_any(x) (x)
+#define VNL_PERLANE(T, name) T name[64]
+#define VNL_AT(name, j) name[j]
+#define VNL_GETF(name, a) name[a]
+#define VNL_GETI(name, a) name[a]
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
   do {                                                                         \
     dim3 g_ = (grid), b_ = (block);                                            \

@@ -41,6 +41,7 @@
 #ifndef VNL_FORKJOIN_DEFINED
 #define VNL_LANES 64
 #define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
+#define VNL_ROWS_SMALL 5    /* specialisation for nefc <= 320 (the rodent has 303) */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
 #define VNL_SERIAL if (lane == 0)
 #define VNL_SYNC() __syncthreads()
@@ -60,6 +61,11 @@ VNL_HD float vnl_wave_sum(float x) {
          __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
 }
 VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
+// one value per lane (item j of a <= 64-item region lives in lane j) + uniform-index broadcast
+#define VNL_PERLANE(T, name) T name
+#define VNL_AT(name, j) name
+#define VNL_GETF(name, a) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, name), a))
+#define VNL_GETI(name, a) __builtin_amdgcn_readlane(name, a)
 #endif
 
 // Diagnostic build only (-DVNL_PROFILE, csrc/build.py --profile): per-stage s_memtime stamps summed
@@ -180,6 +186,8 @@ struct EnvWave {
   VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
   VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
   VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + c]; }
+  // last dof on the path of contact c's body (== nv if the body hangs off the world without dofs)
+  VNL_HD int con_lastdof(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + m.ncon + c]; }
   // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
   VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
   VNL_HD int lvl_start(int l) const { return ((const unsigned char*)(s + L.tab_lvl))[m.nv + l]; }
@@ -196,7 +204,11 @@ struct EnvWave {
       tb[m.nbody + b] = (unsigned char)m.body_dofadr[b];
       tb[2 * m.nbody + b] = (unsigned char)m.body_dofnum[b];
     }
-    VNL_FOR(c, m.ncon) tb[3 * m.nbody + c] = (unsigned char)m.cg_body[m.con_geom[c]];
+    VNL_FOR(c, m.ncon) {
+      int cb = m.cg_body[m.con_geom[c]];
+      tb[3 * m.nbody + c] = (unsigned char)cb;
+      tb[3 * m.nbody + m.ncon + c] = (unsigned char)m.body_lastdof[cb];
+    }
     unsigned char* tl = (unsigned char*)(s + L.tab_lvl);
     VNL_FOR(q, m.nv + m.max_depth + 2) tl[q] = m.lvl_tab[q];
     unsigned char* tj = (unsigned char*)(s + L.tab_jump);
@@ -384,6 +396,9 @@ struct EnvWave {
   // table (ordered by a+c, so a prefix of it enumerates any depth).  The division of row k by its
   // pivot is deferred to one final pass (row k is never touched again after iteration k).
   VNL_HD void factor() const {
+    // (A column-per-lane variant that keeps the pivot row in registers and broadcasts it with
+    // v_readlane was measured 2x slower: one LDS round trip in flight per step.  What matters is the
+    // number of independent LDS accesses in flight, so each lane streams one ancestor row, 8-wide.)
     for (int k = m.nv - 1; k >= 0; k--) {
       int adr_k = madr(k), dk = eadr(k) - adr_k;
       vreal inv = vreal(1.) / s[L.LD + adr_k];
@@ -395,6 +410,14 @@ struct EnvWave {
         const vreal* src = s + L.LD + adr_k + a;
         vreal* dst = s + L.LD + madr(anc_of(adr_k + a));
         int c = 0;
+        for (; c + 8 <= len; c += 8) {  // all 16 loads of a trip are issued before the first store
+          vreal x0 = src[c], x1 = src[c + 1], x2 = src[c + 2], x3 = src[c + 3];
+          vreal x4 = src[c + 4], x5 = src[c + 5], x6 = src[c + 6], x7 = src[c + 7];
+          vreal y0 = dst[c], y1 = dst[c + 1], y2 = dst[c + 2], y3 = dst[c + 3];
+          vreal y4 = dst[c + 4], y5 = dst[c + 5], y6 = dst[c + 6], y7 = dst[c + 7];
+          dst[c] = y0 - tmp * x0, dst[c + 1] = y1 - tmp * x1, dst[c + 2] = y2 - tmp * x2, dst[c + 3] = y3 - tmp * x3;
+          dst[c + 4] = y4 - tmp * x4, dst[c + 5] = y5 - tmp * x5, dst[c + 6] = y6 - tmp * x6, dst[c + 7] = y7 - tmp * x7;
+        }
         for (; c + 4 <= len; c += 4) {
           vreal x0 = src[c], x1 = src[c + 1], x2 = src[c + 2], x3 = src[c + 3];
           vreal y0 = dst[c], y1 = dst[c + 1], y2 = dst[c + 2], y3 = dst[c + 3];
@@ -435,6 +458,15 @@ struct EnvWave {
         const vreal* row = s + L.LD + adr;
         const vreal* ld = s + L.LD + t;
         int u = 1;
+        for (; u + 8 <= t; u += 8) {
+          int b0 = bb[u], b1 = bb[u + 1], b2 = bb[u + 2], b3 = bb[u + 3];
+          int b4 = bb[u + 4], b5 = bb[u + 5], b6 = bb[u + 6], b7 = bb[u + 7];
+          vreal l0 = row[u], l1 = row[u + 1], l2 = row[u + 2], l3 = row[u + 3];
+          vreal l4 = row[u + 4], l5 = row[u + 5], l6 = row[u + 6], l7 = row[u + 7];
+          vreal n0 = ld[b0 - u], n1 = ld[b1 - u - 1], n2 = ld[b2 - u - 2], n3 = ld[b3 - u - 3];
+          vreal n4 = ld[b4 - u - 4], n5 = ld[b5 - u - 5], n6 = ld[b6 - u - 6], n7 = ld[b7 - u - 7];
+          acc -= (l0 * n0 + l1 * n1 + l2 * n2 + l3 * n3) + (l4 * n4 + l5 * n5 + l6 * n6 + l7 * n7);
+        }
         for (; u + 4 <= t; u += 4) {  // loads first, so the four dependent (base -> N) chains overlap
           int b0 = bb[u], b1 = bb[u + 1], b2 = bb[u + 2], b3 = bb[u + 3];
           vreal l0 = row[u], l1 = row[u + 1], l2 = row[u + 2], l3 = row[u + 3];
@@ -720,22 +752,10 @@ struct EnvWave {
     VNL_SYNC();
   }
 
-  // body twists V[b] = sum_{d in path(b)} cdof[d] * vec[d]; returns the LDS offset of V (inside T2)
-  VNL_HD int body_twists(int vec) const {
-    int A = L.T2, Bf = L.T2 + 6 * m.nbody;
-    VNL_FOR(i, 6 * m.nbody) {
-      int b = i / 6, k = i - 6 * b;
-      int da = dofadr_of(b), nd = dofnum_of(b);
-      vreal v = vreal(0.);
-      for (int t = 0; t < nd; t++) v += s[L.cdof + 6 * (da + t) + k] * s[vec + da + t];
-      s[A + i] = v;
-    }
-    VNL_SYNC();
-    return tree_prefix(A, Bf);
-  }
-
-  // out[r] = (J vec)[r]  (accumulate: out[r] += ...), using the twists left by body_twists(vec)
-  VNL_HD void jac_mul(int V, int vec, int out, bool accumulate) const {
+  // out[r] = (J vec)[r]  (accumulate: out[r] += ...).  Limit rows: one lane each.  Contact rows: one
+  // lane per ACTIVE contact; the twist of the contact's body is summed along that body's own dof
+  // path (ancestor list of its last dof), so no tree pass and no synchronisation is needed.
+  VNL_HD void jac_mul(int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     VNL_FOR(r, m.nlimit) {
       vreal v = s[L.lim_sign + r] * s[vec + m.lim_dof[r]];
@@ -745,8 +765,23 @@ struct EnvWave {
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     VNL_FOR(j, na) {
       int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
+      int dl = con_lastdof(c);
+      S6 vel = S6{v3(0, 0, 0), v3(0, 0, 0)};
+      if (dl < m.nv) {
+        int adr = madr(dl), dep = eadr(dl) - adr;
+        const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
+        int t = 0;
+        for (; t + 1 <= dep; t += 2) {  // two independent (index -> cdof, vec) chains per trip
+          int d0 = an[t], d1 = an[t + 1];
+          vreal w0 = s[vec + d0], w1 = s[vec + d1];
+          vel = vel + ld6(L.cdof + 6 * d0) * w0 + ld6(L.cdof + 6 * d1) * w1;
+        }
+        for (; t <= dep; t++) {
+          int d0 = an[t];
+          vel = vel + ld6(L.cdof + 6 * d0) * s[vec + d0];
+        }
+      }
       vreal mu = m.cg_mu[g];
-      S6 vel = ld6(V + 6 * con_body(c));
       V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
       V3 pv = vel.l + cross(vel.a, rel);
       vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
@@ -827,12 +862,14 @@ struct EnvWave {
   struct LsPoint {
     vreal alpha, cost, d0, d1;
   };
+  template <int RPL>
   struct LsRows {
-    vreal ja[VNL_ROWS_PER_LANE], jv[VNL_ROWS_PER_LANE], a0[VNL_ROWS_PER_LANE], a1[VNL_ROWS_PER_LANE], a2[VNL_ROWS_PER_LANE];
+    vreal ja[RPL], jv[RPL], a0[RPL], a1[RPL], a2[RPL];
   };
-  VNL_HD void ls_load(LsRows& R) const {
+  template <int RPL>
+  VNL_HD void ls_load(LsRows<RPL>& R) const {
 #pragma unroll
-    for (int j = 0; j < VNL_ROWS_PER_LANE; j++) {
+    for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool ok = r < m.nefc;
       vreal D = ok ? s[L.efc_D + r] : vreal(0.);
@@ -841,12 +878,12 @@ struct EnvWave {
       R.a0[j] = vreal(0.5) * ja * ja * D, R.a1[j] = jv * ja * D, R.a2[j] = vreal(0.5) * jv * jv * D;
     }
   }
-  template <int N>
-  VNL_HD void ls_eval(const LsRows& R, const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
+  template <int N, int RPL>
+  VNL_HD void ls_eval(const LsRows<RPL>& R, const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
     vreal q0[N], q1[N], q2[N];
     for (int i = 0; i < N; i++) q0[i] = vreal(0.), q1[i] = vreal(0.), q2[i] = vreal(0.);
 #pragma unroll
-    for (int j = 0; j < VNL_ROWS_PER_LANE; j++) {
+    for (int j = 0; j < RPL; j++) {
       for (int i = 0; i < N; i++) {
         bool act = R.ja[j] + alpha[i] * R.jv[j] < vreal(0.);
         q0[i] += act ? R.a0[j] : vreal(0.), q1[i] += act ? R.a1[j] : vreal(0.), q2[i] += act ? R.a2[j] : vreal(0.);
@@ -862,19 +899,51 @@ struct EnvWave {
     }
   }
 
+  // exact line search of solver._linesearch; returns the accepted step length (0 if no improvement)
+  template <int RPL>
+  VNL_HD vreal line_search(vreal gauss, vreal qg1, vreal qg2, vreal gtol) const {
+      LsPoint p0, lo, hi;
+      LsRows<RPL> rows;
+      ls_load(rows);
+      vreal a1[1] = {vreal(0.)};
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
+      a1[0] = p0.alpha - p0.d0 / p0.d1;
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
+      if (lo.d0 < p0.d0) {
+        hi = p0;
+      } else {
+        hi = lo, lo = p0;
+      }
+      bool swap = true;
+      for (int li = 0; li < m.ls_iterations; li++) {
+        if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
+        vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
+        LsPoint p[3];
+        ls_eval<3>(rows, a3, gauss, qg1, qg2, p);
+        bool s1 = (lo.d0 > vreal(0.)) || (lo.d0 < p[0].d0);
+        if (s1) lo = p[0];
+        bool s2 = (p[2].d0 < vreal(0.)) && (lo.d0 < p[2].d0);
+        if (s2) lo = p[2];
+        bool s3 = (hi.d0 < vreal(0.)) || (hi.d0 > p[1].d0);
+        if (s3) hi = p[1];
+        bool s4 = (p[2].d0 > vreal(0.)) && (hi.d0 > p[2].d0);
+        if (s4) hi = p[2];
+        swap = s1 || s2 || s3 || s4;
+      }
+      bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+      return improved ? (lo.cost < hi.cost ? lo.alpha : hi.alpha) : vreal(0.);
+  }
+
   // solver.solve (CG).  One env per wave: the while loops run with this env's own trip counts.
   VNL_HD void solve() const {
     const int nv = m.nv, ne = m.nefc;
-    int V;
     // --- warm start selection: cost at qacc_warmstart vs qacc_smooth.
     // On entry: Jaref holds -aref (make_constraint), mv holds M*warm, qacc holds warm (forward()).
-    V = body_twists(L.qacc_smooth);
-    jac_mul(V, L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
+    jac_mul(L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
     vreal cost_s = constraint_cost(L.Jaref);  // gauss term vanishes: M qacc_smooth = qfrc_smooth
     VNL_FOR(d, nv) s[L.tmp + d] = s[L.qacc + d] - s[L.qacc_smooth + d];
     VNL_SYNC();
-    V = body_twists(L.tmp);
-    jac_mul(V, L.tmp, L.jv, false);  // J (warm - smooth)
+    jac_mul(L.tmp, L.jv, false);  // J (warm - smooth)
     VNL_FOR(r, ne) s[L.jv + r] += s[L.Jaref + r];  // Jaref(warm)
     vreal gw = vreal(0.);
     VNL_FOR(d, nv) gw += (s[L.mv + d] - s[L.smooth + d]) * s[L.tmp + d];
@@ -913,8 +982,7 @@ struct EnvWave {
       // ---- line search
       vreal smag = sqrt(vdot(L.search, L.search)) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
-      V = body_twists(L.search);
-      jac_mul(V, L.search, L.jv, false);
+      jac_mul(L.search, L.jv, false);
       vreal qg1 = vreal(0.), qg2 = vreal(0.);
       VNL_FOR(d, nv) {
         vreal sd = s[L.search + d];
@@ -923,36 +991,8 @@ struct EnvWave {
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(7);
-      LsPoint p0, lo, hi;
-      LsRows rows;
-      ls_load(rows);
-      vreal a1[1] = {vreal(0.)};
-      ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
-      a1[0] = p0.alpha - p0.d0 / p0.d1;
-      ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
-      if (lo.d0 < p0.d0) {
-        hi = p0;
-      } else {
-        hi = lo, lo = p0;
-      }
-      bool swap = true;
-      for (int li = 0; li < m.ls_iterations; li++) {
-        if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
-        vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
-        LsPoint p[3];
-        ls_eval<3>(rows, a3, gauss, qg1, qg2, p);
-        bool s1 = (lo.d0 > vreal(0.)) || (lo.d0 < p[0].d0);
-        if (s1) lo = p[0];
-        bool s2 = (p[2].d0 < vreal(0.)) && (lo.d0 < p[2].d0);
-        if (s2) lo = p[2];
-        bool s3 = (hi.d0 < vreal(0.)) || (hi.d0 > p[1].d0);
-        if (s3) hi = p[1];
-        bool s4 = (p[2].d0 > vreal(0.)) && (hi.d0 > p[2].d0);
-        if (s4) hi = p[2];
-        swap = s1 || s2 || s3 || s4;
-      }
-      bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-      vreal alpha = improved ? (lo.cost < hi.cost ? lo.alpha : hi.alpha) : vreal(0.);
+      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol)
+                                              : line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol);
       VNL_FOR(d, nv) {
         s[L.qacc + d] += alpha * s[L.search + d];
         s[L.Ma + d] += alpha * s[L.mv + d];
@@ -1040,8 +1080,7 @@ struct EnvWave {
     VNL_PROF(5);
     for (int rep = 0; rep < m.dbg_count; rep++) {
       if (m.dbg_stage == 6) {
-        int V = body_twists(L.qacc_smooth);
-        jac_mul(V, L.qacc_smooth, L.jv, false);
+        jac_mul(L.qacc_smooth, L.jv, false);
       } else if (m.dbg_stage == 7) {
         VNL_FOR(d, m.nv) s[L.tmp + d] = s[L.smooth + d];
         VNL_SYNC();
@@ -1049,7 +1088,7 @@ struct EnvWave {
       } else if (m.dbg_stage == 8) {
         vreal a3[3] = {vreal(0.), vreal(1e-4), vreal(2e-4)};
         LsPoint p[3];
-        LsRows rows;
+        LsRows<VNL_ROWS_SMALL> rows;
         ls_load(rows);
         ls_eval<3>(rows, a3, vreal(0.), vreal(0.), vreal(0.), p);
         if (p[0].cost == vreal(-1.)) s[L.tmp] = p[1].cost;  // keep the result alive

@@ -217,6 +217,9 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         if (!in) return fail(VNL_ERR_UNSUPPORTED, "body numbering is not depth-first");
       }
     UPI(body_nsub, nsub)
+    std::vector<int> lastdof(nb, nv);  // last dof on the path from the root to (and including) body b; nv = none
+    for (int b = 1; b < nb; b++) lastdof[b] = dn[b] > 0 ? da[b] + dn[b] - 1 : lastdof[bp[b]];
+    UPI(body_lastdof, lastdof)
     int bdepth = 0;
     for (int b = 1; b < nb; b++) {
       int dd = 0;
@@ -295,7 +298,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     int maxd = 0;
     for (int i = 0; i < nv; i++) maxd = depth[i] > maxd ? depth[i] : maxd;
     d.max_depth = maxd;
-    if (nv > 255 || nb > 255 || maxd > 254) return fail(VNL_ERR_UNSUPPORTED, "model too large for 8-bit index tables");
+    if (nv > 255 || nb > 255 || maxd > 62) return fail(VNL_ERR_UNSUPPORTED, "model too large for 8-bit index tables");
     std::vector<unsigned char> lvl_tab;  // dofs sorted by depth, then the level start offsets
     std::vector<int> lvl_start(maxd + 2, 0);
     for (int lev = 0; lev <= maxd; lev++) {
@@ -381,7 +384,7 @@ static void layout(vnl_env* env) {
   L.Jaref = sec("Jaref", d.nefc), L.jv = sec("jv", d.nefc + pad);
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
   L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
-  L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + d.ncon));
+  L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
   L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
   L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));

@@ -27,7 +27,7 @@ struct DevModel {
   vreal total_mass_inv;
   vreal root_px, root_py, root_pz; /* reference point when the root is not a free joint */
   // bodies
-  const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub;
+  const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub, *body_lastdof;
   const unsigned char* jump; /* [jump_rounds][nbody]: 2^r-th ancestor body, 0 = none */
   const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
   // joints
