@@ -41,6 +41,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_LANES 1
 #define VNL_ROWS_PER_LANE 512
 #define VNL_ROWS_SMALL 320
+#define VNL_PREFIX_PER_LANE 512
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)
 #define VNL_SYNC()

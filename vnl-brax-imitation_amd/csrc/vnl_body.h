@@ -42,6 +42,7 @@
 #define VNL_LANES 64
 #define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
 #define VNL_ROWS_SMALL 5    /* specialisation for nefc <= 320 (the rodent has 303) */
+#define VNL_PREFIX_PER_LANE 8 /* 6 * nbody <= 512 elements per in-place tree prefix */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
 #define VNL_SERIAL if (lane == 0)
 #define VNL_SYNC() __syncthreads()
@@ -174,13 +175,25 @@ struct EnvWave {
     return S6{ang, lin};
   }
 
+  // xpos / xquat / qfrc_actuator live in their (caller-owned, L2-resident) state buffers, not in LDS
+  VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * m.nbody; }
+  VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * m.nbody; }
+  VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * m.nv; }
+  VNL_HD V3 gpos3(int b) const {
+    const vreal* x = gxpos() + 3 * b;
+    return V3{x[0], x[1], x[2]};
+  }
+  VNL_HD Q4 gquat4(int b) const {
+    const vreal* q = gxquat() + 4 * b;
+    return Q4{q[0], q[1], q[2], q[3]};
+  }
   VNL_HD V3 ref_point() const { return m.root_free ? ld3(L.qpos) : V3{m.root_px, m.root_py, m.root_pz}; }
 
   // ---- small index tables staged in LDS (dependent lookups in the sparse linear algebra and in the
   // tree walks would otherwise each pay a global / scalar-cache round trip)
   VNL_HD int anc_of(int k) const { return ((const unsigned char*)(s + L.tab_anc))[k]; }  // column dof of entry k
-  VNL_HD int madr(int d) const { return ((const int*)(s + L.tab_madr))[d]; }              // first entry of row d
-  VNL_HD int eadr(int d) const { return ((const int*)(s + L.tab_E))[d]; }                 // madr(d) + depth(d)
+  VNL_HD int madr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[d]; }            // first entry of row d
+  VNL_HD int eadr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[m.nv + d]; }     // madr(d) + depth(d)
   VNL_HD int depth(int d) const { return eadr(d) - madr(d); }
   VNL_HD int parent_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[b]; }
   VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
@@ -195,9 +208,8 @@ struct EnvWave {
   VNL_HD void load_tables() const {
     unsigned char* ta = (unsigned char*)(s + L.tab_anc);
     VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
-    int* tm = (int*)(s + L.tab_madr);
-    int* te = (int*)(s + L.tab_E);
-    VNL_FOR(d, m.nv) tm[d] = m.dof_Madr[d], te[d] = m.dof_Madr[d] + m.dof_depth[d];
+    unsigned short* tm = (unsigned short*)(s + L.tab_madr);
+    VNL_FOR(d, m.nv) tm[d] = (unsigned short)m.dof_Madr[d], tm[m.nv + d] = (unsigned short)(m.dof_Madr[d] + m.dof_depth[d]);
     unsigned char* tb = (unsigned char*)(s + L.tab_body);
     VNL_FOR(b, m.nbody) {
       tb[b] = (unsigned char)m.body_parent[b];
@@ -236,6 +248,25 @@ struct EnvWave {
     return src;
   }
 
+  // In-place variant (one buffer): every element first reads its own and its jump-ancestor's value
+  // into registers, then -- after a barrier -- writes the sum back.
+  VNL_HD void tree_prefix_inplace(int buf) const {
+    for (int r = 0; r < m.jump_rounds; r++) {
+      vreal keep[VNL_PREFIX_PER_LANE];
+      int n = 6 * m.nbody, q = 0;
+      VNL_FOR(i, n) {
+        int b = i / 6, j = jump_of(r, b);
+        vreal v = s[buf + i];
+        if (j > 0) v += s[buf + 6 * j + (i - 6 * b)];
+        keep[q++] = v;
+      }
+      VNL_SYNC();
+      q = 0;
+      VNL_FOR(i, n) s[buf + i] = keep[q++];
+      VNL_SYNC();
+    }
+  }
+
   // smooth.kinematics in three fork-join phases:
   //  (1) per body, in parallel: its transform relative to the parent frame as a function of its own
   //      joint angles (MJX's anchor / off-centre rotation rule applied in the parent frame), plus the
@@ -244,7 +275,7 @@ struct EnvWave {
   //      jumping (log2(depth) rounds) -- composition of rigid transforms is associative;
   //  (3) per dof, in parallel: cdof from the parent's world pose and the local anchor / axis.
   VNL_HD void kinematics() const {
-    int A = L.T1, Bf = L.T2;  // 7 floats per body: pos(3) quat(4)
+    int A = L.P, Bf = L.P + 7 * m.nbody;  // 7 floats per body: pos(3) quat(4)
     VNL_FOR(b, m.nbody) {
       V3 pos = v3(vreal(0.), vreal(0.), vreal(0.));
       Q4 quat = Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)};
@@ -294,18 +325,20 @@ struct EnvWave {
       int t = src;
       src = dst, dst = t;
     }
+    vreal* gx = gxpos();
+    vreal* gq = gxquat();
     VNL_FOR(b, m.nbody) {
-      st3(L.xpos + 3 * b, ld3(src + 7 * b));
+      V3 p = ld3(src + 7 * b);
       Q4 q = ld4(src + 7 * b + 3);
-      s[L.xquat + 4 * b] = q.w, s[L.xquat + 4 * b + 1] = q.x, s[L.xquat + 4 * b + 2] = q.y, s[L.xquat + 4 * b + 3] = q.z;
+      gx[3 * b] = p.x, gx[3 * b + 1] = p.y, gx[3 * b + 2] = p.z;
+      gq[4 * b] = q.w, gq[4 * b + 1] = q.x, gq[4 * b + 2] = q.y, gq[4 * b + 3] = q.z;
     }
-    VNL_SYNC();
     V3 O = ref_point();
     VNL_FOR(j, m.njnt) {
       int bd = m.jnt_body[j], da = m.jnt_dofadr[j];
       if (m.jnt_type[j] == VNL_JNT_FREE) {
-        M3 R = qmat(ld4(L.xquat + 4 * bd));
-        V3 off = O - ld3(L.xpos + 3 * bd);
+        M3 R = qmat(ld4(src + 7 * bd + 3));
+        V3 off = O - ld3(src + 7 * bd);
         for (int t = 0; t < 3; t++) {
           int o = L.cdof + 6 * (da + t);
           s[o] = vreal(0.), s[o + 1] = vreal(0.), s[o + 2] = vreal(0.);
@@ -318,28 +351,28 @@ struct EnvWave {
         }
       } else {
         int p = parent_of(bd);
-        Q4 pq = ld4(L.xquat + 4 * p);
+        Q4 pq = ld4(src + 7 * p + 3);
         S6 la = ld6(L.cdof + 6 * da);
-        V3 axis = qrot(la.a, pq), anchor = ld3(L.xpos + 3 * p) + qrot(la.l, pq);
+        V3 axis = qrot(la.a, pq), anchor = ld3(src + 7 * p) + qrot(la.l, pq);
         st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
       }
     }
     VNL_SYNC();
   }
 
-  // com_pos: cinert about O in world axes, R I R' + m(|r|^2 1 - r r'), r = xipos - O -> T1; optionally com
+  // com_pos: cinert about O in world axes, R I R' + m(|r|^2 1 - r r'), r = xipos - O -> pool[0..10 nbody); optionally com
   VNL_HD void body_inertias(bool with_com) const {
     V3 O = ref_point();
     V3 csum = v3(vreal(0.), vreal(0.), vreal(0.));
     VNL_FOR(b, m.nbody) {
-      int o = L.T1 + 10 * b;
+      int o = L.P + 10 * b;
       if (b == 0) {
         for (int k = 0; k < 10; k++) s[o + k] = vreal(0.);
         continue;
       }
-      M3 R = qmat(ld4(L.xquat + 4 * b));
+      M3 R = qmat(gquat4(b));
       vreal mass = m.body_mass[b];
-      V3 xip = ld3(L.xpos + 3 * b) + mmul(R, t3(m.body_ipos, b));
+      V3 xip = gpos3(b) + mmul(R, t3(m.body_ipos, b));
       csum = csum + xip * mass;
       V3 r = xip - O;
       const vreal* I6 = m.body_inertia6 + 6 * b;  // xx yy zz xy xz yz (body axes, about ipos)
@@ -377,11 +410,11 @@ struct EnvWave {
 
   // ------------------------------------------------------------------ inertia
   // smooth.crb + make_m straight into the factor buffer: LD <- qM + diag_scale * diag(damping).
-  // Expects cinert in T1 (turned into crb in place).
+  // Expects cinert in pool[0..10 nbody) (turned into crb in place).
   VNL_HD void mass_matrix(vreal diag_scale) const {
-    tree_accumulate(L.T1, 10);
+    tree_accumulate(L.P, 10);
     VNL_FOR(i, m.nv) {
-      S6 f = inert_mul(L.T1 + 10 * m.dof_body[i], ld6(L.cdof + 6 * i));
+      S6 f = inert_mul(L.P + 10 * m.dof_body[i], ld6(L.cdof + 6 * i));
       int adr = madr(i), dep = eadr(i) - adr;
       s[L.LD + adr] = dot(f, ld6(L.cdof + 6 * i)) + m.dof_armature[i] + diag_scale * m.dof_damping[i];
 #pragma unroll 2
@@ -514,7 +547,7 @@ struct EnvWave {
     VNL_FOR(a, m.nv) {
       int da = eadr(a) - madr(a), nd = m.dof_ndesc[a];
       vreal acc = s[in + a];
-      const int* ea = (const int*)(s + L.tab_E);
+      const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
       const vreal* ld = s + L.LD - da;
       int i = a + 1, iend = a + nd;
       for (; i + 3 <= iend; i += 4) {
@@ -551,16 +584,18 @@ struct EnvWave {
   // make_constraint).  Needs cinert in T1.
   VNL_HD int bias_forces() const {
     int nb6 = 6 * m.nbody;
+    int X0 = L.P + 10 * m.nbody, X1 = X0 + nb6;  // after cinert; cvel has to end in X1 (X0 is reused)
+    int start = (m.jump_rounds & 1) ? X0 : X1;
     VNL_FOR(i, nb6) {
       int b = i / 6, k = i - 6 * b;
       int da = dofadr_of(b), nd = dofnum_of(b);
       vreal v = vreal(0.);
       for (int t = 0; t < nd; t++) v += s[L.cdof + 6 * (da + t) + k] * s[L.qvel + da + t];
-      s[L.T2 + i] = v;
+      s[start + i] = v;
     }
     VNL_SYNC();
-    int cv = tree_prefix(L.T2, L.T2 + nb6);
-    int E0 = L.efc_D, E1 = L.efc_D + nb6;
+    int cv = tree_prefix(start, start == X0 ? X1 : X0);  // == X1
+    int ca = X0;
     VNL_FOR(b, m.nbody) {  // own acceleration term: sum over the body's dofs of cdof_dot * qvel
       S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
       if (b > 0) {
@@ -585,32 +620,32 @@ struct EnvWave {
           }
         }
       }
-      st6(E0 + 6 * b, acc);
+      st6(ca + 6 * b, acc);
     }
     VNL_SYNC();
-    int ca = tree_prefix(E0, E1);
-    int cf = ca == E0 ? E1 : E0;
-    VNL_FOR(b, m.nbody) {
+    tree_prefix_inplace(ca);
+    VNL_FOR(b, m.nbody) {  // cfrc overwrites cacc in place (each body only needs its own entries)
       if (b == 0) {
-        st6(cf, S6{v3(0, 0, 0), v3(0, 0, 0)});
+        st6(ca, S6{v3(0, 0, 0), v3(0, 0, 0)});
         continue;
       }
       S6 vel = ld6(cv + 6 * b), acc = ld6(ca + 6 * b);
       acc.l = acc.l + v3(-m.gx, -m.gy, -m.gz);  // cacc of the world body, inherited by every body
-      st6(cf + 6 * b, inert_mul(L.T1 + 10 * b, acc) + mcross_force(vel, inert_mul(L.T1 + 10 * b, vel)));
+      st6(ca + 6 * b, inert_mul(L.P + 10 * b, acc) + mcross_force(vel, inert_mul(L.P + 10 * b, vel)));
     }
     VNL_SYNC();
-    tree_accumulate(cf, 6);
+    tree_accumulate(ca, 6);
     // qfrc_smooth starts as passive damping minus the bias force (springs / actuation added by smooth_forces)
     VNL_FOR(d, m.nv)
-      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - dot(ld6(L.cdof + 6 * d), ld6(cf + 6 * m.dof_body[d]));
+      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - dot(ld6(L.cdof + 6 * d), ld6(ca + 6 * m.dof_body[d]));
     VNL_SYNC();
     return cv;
   }
 
   // passive + actuation + qfrc_smooth + qacc_smooth
   VNL_HD void smooth_forces() const {
-    VNL_FOR(d, m.nv) s[L.qfrc_act + d] = vreal(0.);
+    const int qa_tmp = L.Ma;  // free until the solver starts
+    VNL_FOR(d, m.nv) s[qa_tmp + d] = vreal(0.);
     VNL_SYNC();
     VNL_FOR(j, m.njnt) {
       if (m.jnt_type[j] == VNL_JNT_HINGE) {
@@ -626,12 +661,15 @@ struct EnvWave {
           a = s[L.act + i];
           s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
         }
-        s[L.qfrc_act + m.act_dof[i]] += m.act_gear[i] * m.act_gain[i] * a;
+        s[qa_tmp + m.act_dof[i]] += m.act_gear[i] * m.act_gain[i] * a;
       }
     }
     VNL_SYNC();
+    vreal* gf = gqfrc_act();
     VNL_FOR(d, m.nv) {
-      vreal v = s[L.smooth + d] + s[L.qfrc_act + d];
+      vreal fa = s[qa_tmp + d];
+      gf[d] = fa;
+      vreal v = s[L.smooth + d] + fa;
       s[L.smooth + d] = v;
       s[L.qacc_smooth + d] = v;
     }
@@ -678,14 +716,14 @@ struct EnvWave {
       vreal k, b, imp;
       kbimp(m.lim_solref + 2 * r, m.lim_solimp + 5 * r, m.dt, pos, k, b, imp);
       vreal R = fmax(m.lim_invweight[r] * (vreal(1.) - imp) / imp, VNL_MINVAL);
-      s[L.lim_sign + r] = sign;
-      s[L.efc_D + r] = pos < vreal(0.) ? vreal(1.) / R : vreal(0.);
+      // the sign of the limit Jacobian (+1 lower / -1 upper side) rides on efc_D: D = 0 <=> row absent
+      s[L.efc_D + r] = pos < vreal(0.) ? sign / R : vreal(0.);
       s[L.Jaref + r] = b * (sign * s[L.qvel + m.lim_dof[r]]) + k * imp * pos;  // -aref
     }
     VNL_FOR(g, m.ncg) {
       int bd = m.cg_body[g], c0 = m.cg_conadr[g], type = m.cg_type[g];
-      Q4 bq = ld4(L.xquat + 4 * bd);
-      V3 gpos = ld3(L.xpos + 3 * bd) + qrot(t3(m.cg_pos, g), bq);
+      Q4 bq = gquat4(bd);
+      V3 gpos = gpos3(bd) + qrot(t3(m.cg_pos, g), bq);
       M3 R = qmat(qmul(bq, t4(m.cg_quat, g)));
       V3 size = t3(m.cg_size, g);
       vreal dist0 = vreal(0.), dist1 = vreal(0.);
@@ -727,7 +765,7 @@ struct EnvWave {
         V3 rel = (q == 0 ? cpos0 : cpos1) - O;
         vreal d = dist - margin;
         st3(L.con_r + 3 * c, rel);
-        st3(L.con_t1 + 3 * c, t1);
+        if (q == 0) st3(L.con_t1 + 3 * g, t1);
         vreal k, b, imp;
         kbimp(m.cg_solref + 2 * g, m.cg_solimp + 5 * g, m.dt, d, k, b, imp);
         vreal Rr = fmax(invw * (vreal(1.) - imp) / imp, VNL_MINVAL);
@@ -758,7 +796,7 @@ struct EnvWave {
   VNL_HD void jac_mul(int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     VNL_FOR(r, m.nlimit) {
-      vreal v = s[L.lim_sign + r] * s[vec + m.lim_dof[r]];
+      vreal v = copysign(vreal(1.), s[L.efc_D + r]) * s[vec + m.lim_dof[r]];
       s[out + r] = accumulate ? s[out + r] + v : v;
     }
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
@@ -782,7 +820,7 @@ struct EnvWave {
         }
       }
       vreal mu = m.cg_mu[g];
-      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
+      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
       V3 pv = vel.l + cross(vel.a, rel);
       vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
       vreal o0 = jn + j1, o1 = jn - j1, o2 = jn + j2, o3 = jn - j2;
@@ -797,7 +835,7 @@ struct EnvWave {
     vreal c = vreal(0.);
     VNL_FOR(r, m.nefc) {
       vreal x = s[jaref + r];
-      c += x < vreal(0.) ? s[L.efc_D + r] * x * x : vreal(0.);
+      c += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
     }
     return vreal(0.5) * vnl_wave_sum(c);
   }
@@ -809,13 +847,13 @@ struct EnvWave {
   // built by make_constraint).
   VNL_HD vreal constraint_force() const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    int Wc = L.T1;
+    int Wc = L.P + 3 * m.nefc;  // after efc_D | Jaref | jv
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     vreal cost = vreal(0.);
     VNL_FOR(r, m.nlimit) {
       vreal x = s[L.Jaref + r];
-      cost += x < vreal(0.) ? s[L.efc_D + r] * x * x : vreal(0.);
+      cost += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
     }
     VNL_FOR(j, na) {
       int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
@@ -826,7 +864,7 @@ struct EnvWave {
         f[q] = x < vreal(0.) ? -D * x : vreal(0.);
         cost += x < vreal(0.) ? D * x * x : vreal(0.);
       }
-      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * c), t2 = cross(n, t1);
+      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
       V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
       st6(Wc + 6 * j, S6{cross(rel, Fw), Fw});
     }
@@ -842,7 +880,7 @@ struct EnvWave {
       int r = m.dof_limrow[d];
       if (r >= 0) {
         vreal x = s[L.Jaref + r];
-        q += x < vreal(0.) ? s[L.lim_sign + r] * (-s[L.efc_D + r] * x) : vreal(0.);
+        q += x < vreal(0.) ? -s[L.efc_D + r] * x : vreal(0.);  // sign(D) is the limit Jacobian entry
       }
       s[L.qfrc_c + d] = q;
     }
@@ -872,7 +910,7 @@ struct EnvWave {
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool ok = r < m.nefc;
-      vreal D = ok ? s[L.efc_D + r] : vreal(0.);
+      vreal D = ok ? fabs(s[L.efc_D + r]) : vreal(0.);
       vreal ja = ok ? s[L.Jaref + r] : vreal(0.), jv = ok ? s[L.jv + r] : vreal(0.);
       R.ja[j] = ja, R.jv[j] = jv;
       R.a0[j] = vreal(0.5) * ja * ja * D, R.a1[j] = jv * ja * D, R.a2[j] = vreal(0.5) * jv * jv * D;
@@ -1184,17 +1222,16 @@ struct EnvWave {
     vreal* gv = st.qvel + (size_t)e * m.nv;
     vreal* ga = st.act + (size_t)e * m.nu;
     vreal* gw = st.warm + (size_t)e * m.nv;
-    vreal* gf = st.qfrc_actuator + (size_t)e * m.nv;
-    vreal* gx = st.xpos + (size_t)e * 3 * m.nbody;
-    vreal* gxq = st.xquat + (size_t)e * 4 * m.nbody;
+    const vreal* gf = gqfrc_act();
+    const vreal* gx = gxpos();
     bool bad = false;
     VNL_FOR(i, m.nq) {
       vreal v = s[L.qpos + i];
       gq[i] = v, bad |= v != v;
     }
     VNL_FOR(i, m.nv) {
-      vreal a = s[L.qvel + i], b = s[L.qacc + i], c = s[L.qfrc_act + i];
-      gv[i] = a, gw[i] = b, gf[i] = c;
+      vreal a = s[L.qvel + i], b = s[L.qacc + i], c = gf[i];
+      gv[i] = a, gw[i] = b;
       bad |= (a != a) | (b != b) | (c != c);
     }
     VNL_FOR(i, m.nu) {
@@ -1202,10 +1239,9 @@ struct EnvWave {
       ga[i] = v, bad |= v != v;
     }
     VNL_FOR(i, 3 * m.nbody) {
-      vreal v = s[L.xpos + i];
-      gx[i] = v, bad |= v != v;
+      vreal v = gx[i];
+      bad |= v != v;
     }
-    VNL_FOR(i, 4 * m.nbody) gxq[i] = s[L.xquat + i];
     VNL_FOR(i, 3) {
       vreal v = s[L.com + i];
       st.com1[(size_t)e * 3 + i] = v, bad |= v != v;
@@ -1218,14 +1254,17 @@ struct EnvWave {
     vreal* o = st.obs + (size_t)e * ev.obs_size;
     VNL_FOR(i, m.nq) o[i] = nan0(s[L.qpos + i]);
     VNL_FOR(i, m.nv) o[m.nq + i] = nan0(s[L.qvel + i]);
-    VNL_FOR(i, m.nv) o[m.nq + m.nv + i] = nan0(s[L.qfrc_act + i]);
-    VNL_FOR(k, 3 * ev.nee) o[m.nq + 2 * m.nv + k] = nan0(s[L.xpos + 3 * ev.end_eff_idx[k / 3] + k % 3]);
+    const vreal* gf = gqfrc_act();
+    const vreal* gx = gxpos();
+    VNL_FOR(i, m.nv) o[m.nq + m.nv + i] = nan0(gf[i]);
+    VNL_FOR(k, 3 * ev.nee) o[m.nq + 2 * m.nv + k] = nan0(gx[3 * ev.end_eff_idx[k / 3] + k % 3]);
   }
 
   // rodent.py:346-448; local frame = v @ xmat[1]
   VNL_HD void write_traj(int clip, int frame) const {
     int Lr = ev.ref_len, s0 = clampi(frame + 1, 0, ev.T - Lr), nj = m.nq - 7;
-    M3 R = qmat(ld4(L.xquat + 4));
+    M3 R = qmat(gquat4(1));
+    const vreal* gx = gxpos();
     size_t fb = (size_t)clip * ev.T + s0;
     vreal* tr = st.traj + (size_t)e * ev.traj_size;
     int n_app = Lr * ev.napp * 3, n_bod = Lr * ev.nb * 3, n_root = Lr * 3, n_j = Lr * ev.njc;
@@ -1236,7 +1275,7 @@ struct EnvWave {
     VNL_FOR(k, Lr * ev.nb) {  // bodies: local block then global block
       int t = k / ev.nb, b = k % ev.nb, bd = ev.body_idxs[b];
       const float* cb = ev.body_positions + ((fb + t) * ev.nb + b) * 3;
-      V3 v = V3{vreal(cb[0]) - s[L.xpos + 3 * bd], vreal(cb[1]) - s[L.xpos + 3 * bd + 1], vreal(cb[2]) - s[L.xpos + 3 * bd + 2]};
+      V3 v = V3{vreal(cb[0]) - gx[3 * bd], vreal(cb[1]) - gx[3 * bd + 1], vreal(cb[2]) - gx[3 * bd + 2]};
       vreal* lo = tr + n_app + 3 * k;
       lo[0] = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
       lo[1] = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
@@ -1278,7 +1317,7 @@ struct EnvWave {
     store_state();
     write_traj(clip, sf);
     write_obs();
-    vreal term = termination(clip, sf, s + L.qpos, s + L.xpos);
+    vreal term = termination(clip, sf, s + L.qpos, gxpos());
     VNL_SERIAL {
       st.reward[e] = vreal(0.), st.done[e] = vreal(0.);
       for (int k = 0; k < 7; k++) st.metrics[(size_t)e * 7 + k] = vreal(0.);
@@ -1331,12 +1370,12 @@ struct EnvWave {
     vreal dist = fmin(vreal(1.), vreal(2.) * dq * dq - vreal(1.));
     vreal rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
     acc = vreal(0.);
-    VNL_FOR(d, m.nv) acc += s[L.qfrc_act + d] * s[L.qfrc_act + d];
+    VNL_FOR(d, m.nv) acc += gqfrc_act()[d] * gqfrc_act()[d];
     vreal ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
     acc = vreal(0.);
     VNL_FOR(k, 3 * ev.napp) {
       int a = k / 3, i = k % 3;
-      vreal x = s[L.xpos + 3 * ev.app_body[a] + i] - vreal(cb[3 * ev.app_ref_col[a] + i]);
+      vreal x = gxpos()[3 * ev.app_body[a] + i] - vreal(cb[3 * ev.app_ref_col[a] + i]);
       acc += x * x;
     }
     vreal rapp = exp(vreal(-400.) * sqrt(vnl_wave_sum(acc)));

@@ -356,6 +356,8 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   return VNL_OK;
 }
 
+static int imax(int a, int b) { return a > b ? a : b; }
+
 static void layout(vnl_env* env) {
   const DevModel& d = env->dm;
   WsLayout& L = env->L;
@@ -366,25 +368,21 @@ static void layout(vnl_env* env) {
     o += n;
     return at;
   };
-  L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
-  L.actdot = sec("act_dot", d.nu), L.xpos = sec("xpos", 3 * d.nbody), L.xquat = sec("xquat", 4 * d.nbody);
-  L.com = sec("subtree_com1", 4);
-  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
-  L.T1 = sec("T1", 10 * d.nbody);
-  L.T2 = sec("T2", 12 * d.nbody);
-  L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv);
-  L.qacc = sec("qacc", d.nv), L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv);
-  L.search = sec("search", d.nv), L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv);
-  L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv), L.qfrc_act = sec("qfrc_actuator", d.nv);
-  L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncon);
-  L.lim_sign = sec("lim_sign", d.nlimit);
-  L.efc_D = sec("efc_D", d.nefc);
-  // Jaref | jv are contiguous: together they double as cfrc (6*nbody) during the bias pass
-  int pad = 6 * d.nbody > 2 * d.nefc ? 6 * d.nbody - 2 * d.nefc : 0;
-  L.Jaref = sec("Jaref", d.nefc), L.jv = sec("jv", d.nefc + pad);
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
+  L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
+  L.actdot = sec("act_dot", d.nu), L.com = sec("subtree_com1", 4);
+  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
+  int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + 6 * d.ncon);
+  L.P = sec("pool", pool);
+  L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
+  env->sections["efc_D"] = {L.efc_D, d.nefc}, env->sections["Jaref"] = {L.Jaref, d.nefc};
+  env->sections["jv"] = {L.jv, d.nefc};
+  L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv), L.qacc = sec("qacc", d.nv);
+  L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv), L.search = sec("search", d.nv);
+  L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv), L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv);
+  L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncg);
   L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
-  L.tab_E = sec("tab_E", words(4 * (size_t)d.nv)), L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
+  L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
   L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
   L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));
@@ -458,6 +456,10 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   if (const char* padk = getenv("VNL_DBG_LDS_BYTES")) {  // occupancy experiments only: force a larger LDS request
     size_t want = (size_t)atol(padk);
     if (want > env->lds_bytes) env->lds_bytes = want;
+  }
+  if (6 * d.nbody > 512) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_UNSUPPORTED, "more than 85 bodies (in-place tree prefix keeps 8 elements per lane)");
   }
   if (d.nefc > 512) {
     vnl_env_destroy(env);

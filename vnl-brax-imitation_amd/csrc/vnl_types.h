@@ -67,17 +67,17 @@ struct DevState {
 
 // per-env LDS sections (offsets in vreal elements)
 struct WsLayout {
-  int qpos, qvel, act, ctrl, actdot, xpos, xquat, com;
+  int qpos, qvel, act, ctrl, actdot, com;
   int cdof, LD, dinv;
-  int T1;  /* 10*nbody: cinert -> crb | per-contact wrenches in the solver */
-  int T2;  /* 12*nbody: cvel | cacc (-> per-dof crb*cdof) ; in the solver: twists V | wrenches W */
-  int smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2, qfrc_act;
-  int tab_anc, tab_madr, tab_E, tab_body; /* index tables (bytes / ints) staged in LDS */
-  int tab_jump;                           /* jump_rounds * nbody bytes */
-  int tab_lvl;                            /* nv + max_depth + 2 bytes */
-  int act_list;                           /* ncon bytes: contacts with D != 0, then their count (int) */
-  int con_r, con_t1;
-  int lim_sign;
-  int efc_D, Jaref, jv; /* Jaref|jv doubles as cfrc (6*nbody) during the bias pass */
+  // One liveness-aliased pool:
+  //   kinematics : two 7*nbody pose buffers            bias   : cinert 10nb | cacc/cfrc 6nb | cvel 6nb
+  //   M build    : crb (in place of cinert)            solver : efc_D | Jaref | jv (3 nefc) | contact wrenches 6 ncon
+  //   euler      : cinert/crb again
+  int P;
+  int efc_D, Jaref, jv; /* = P, P + nefc, P + 2 nefc */
+  int smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2;
+  int con_r, con_t1;    /* 3 per contact / 3 per collidable geom */
+  int tab_anc, tab_madr, tab_body, tab_jump, tab_lvl; /* 8/16-bit index tables staged in LDS */
+  int act_list;         /* ncon bytes: contacts with D != 0, then their count (int) */
   int total;
 };
