@@ -60,7 +60,7 @@ def build_hostsim(real: str = "float") -> str:
 
 @functools.lru_cache(maxsize=None)
 def hostsim_library(real: str = "float") -> C.CDLL:
-    return _lib.load_library(build_hostsim(real))
+    return _lib.load_library(build_hostsim(real), env_only=True)
 
 
 def hostsim_env(num_envs: int, real: str = "float", **over):

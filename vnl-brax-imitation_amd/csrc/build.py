@@ -6,8 +6,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["vnl_lib.hip"]
-DEPS = ["vnl_lib.hip", "vnl_body.h", "vnl_types.h", "vnl_policy.h", "vnl_policy_impl.h", "../../include/vnl.h"]
+SOURCES = ["vnl_lib.hip", "vnl_policy.hip"]
+DEPS = ["vnl_lib.hip", "vnl_policy.hip", "vnl_body.h", "vnl_types.h", "../../include/vnl.h"]
 OUT = os.path.join(HERE, "libvnl.so")
 
 

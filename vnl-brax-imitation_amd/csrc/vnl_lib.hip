@@ -12,7 +12,6 @@
 
 #include "../../include/vnl.h"
 #include "vnl_body.h"
-#include "vnl_policy.h"
 
 // ----------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -27,6 +26,7 @@ static int fail(int code, const char* fmt, const char* a = "", const char* b = "
   } while (0)
 
 extern "C" const char* vnl_last_error(void) { return g_err; }
+void vnl_set_error_(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }  // used by vnl_policy.hip
 extern "C" int vnl_version(void) { return 1; }
 
 // ----------------------------------------------------------------------------- blob
@@ -579,5 +579,4 @@ extern "C" int vnl_prof_read(unsigned long long* out) {
 }
 #endif
 
-// ----------------------------------------------------------------------------- policy
-#include "vnl_policy_impl.h"
+// the policy-forward entry points (vnl_policy_*) live in vnl_policy.hip

@@ -67,6 +67,8 @@ class PPOImitationNetworks:
     parametric_action_distribution: distribution.NormalTanhDistribution
     policy_module: ipn.IntentionNetwork = None
     value_module: ValueMLP = None
+    normalizes: bool = False  # preprocess_observations_fn is running_statistics.normalize
+    hip_ok: bool = False      # the fused HIP inference kernel computes the same function
 
 
 def make_intention_ppo_networks(
@@ -99,6 +101,8 @@ def make_intention_ppo_networks(
         parametric_action_distribution=dist,
         policy_module=pol,
         value_module=val,
+        normalizes=preprocess_observations_fn is running_statistics.normalize,
+        hip_ok=preprocess_observations_fn in (running_statistics.normalize, identity_observation_preprocessor),
     )
 
 
@@ -115,10 +119,41 @@ def make_inference_fn(ppo_networks: PPOImitationNetworks):
       eps_action ~ N(0,I) for sample_no_postprocessing (ppo_networks.py:60-62),
       one (action_size,) U(-1,1) draw broadcast over the batch for rand_log_prob (:67-73)."""
 
-    def make_policy(params, deterministic: bool = False):
+    hip_cache = {}
+
+    def make_policy(params, deterministic: bool = False, backend: str = "auto"):
+        """backend: "hip" = fused MFMA inference kernel (vnl_policy_forward), "torch" = hipBLASLt ops,
+        "auto" = hip on a HIP device when the observation preprocessor is the running-statistics
+        normaliser or the identity."""
         normalizer_params, policy_params = params
         dist = ppo_networks.parametric_action_distribution
         latent = ppo_networks.policy_module.latents
+        use_hip = backend == "hip" or (backend == "auto" and policy_params.is_cuda and ppo_networks.hip_ok)
+
+        @torch.no_grad()
+        def policy_hip(trajectories, observations, key_sample=None):
+            from .hip_policy import HipIntentionPolicy
+
+            dev, B = observations.device, observations.shape[0]
+            k = (dev, B)
+            if k not in hip_cache:
+                hip_cache[k] = HipIntentionPolicy(ppo_networks.policy_module, dist.event_size, B, dev)
+            eps_latent = _randn((B, latent), key_sample, dev)
+            eps_action = None if deterministic else _randn((B, dist.event_size), key_sample, dev)
+            mean = std = None
+            if ppo_networks.normalizes and normalizer_params is not None:
+                mean, std = normalizer_params.mean, normalizer_params.std
+            action, extras = hip_cache[k].forward(policy_params.detach(), mean, std, trajectories, observations,
+                                                  eps_latent, eps_action, deterministic)
+            if deterministic:
+                return action, {}
+            u = torch.rand((dist.event_size,), generator=key_sample if (key_sample is None or key_sample.device.type == "cpu") else None)
+            random_actions = (u * 2 - 1).to(dev)
+            extras["rand_log_prob"] = dist.log_prob(extras["logits"], random_actions.expand_as(extras["raw_action"]))
+            return action, {k2: extras[k2] for k2 in ("log_prob", "rand_log_prob", "raw_action", "logits")}
+
+        if use_hip:
+            return policy_hip
 
         @torch.no_grad()
         def policy(trajectories: torch.Tensor, observations: torch.Tensor,
