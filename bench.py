@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: rodent-imitation rollout, env-steps/sec, 4096 envs per GPU.
 
-One "step" = one control step (RodentTracking.step: 5 physics substeps + obs / traj /
-reward / termination) for all envs of a rank, driven by pre-generated random actions
-clip(0.3*N(0,1), -1, 1) (the protocol of the reference's notebooks/test_rodent.ipynb),
-with brax-style auto-reset active.  Inputs are resident in HBM before the timed region.
+One "step" = one pass of the hot path of SURVEY.md 3.1 over all envs of a rank:
+intention-policy forward (fused HIP kernel) -> RodentTracking.step (ONE HIP kernel: 5 physics
+substeps + obs / traj / reward / termination) -> brax Episode/AutoReset wrappers -> Transition
+row written into the unroll buffers (acting.actor_step / generate_unroll, unroll_length 20).
+Weights are freshly initialised (no checkpoints offline); the state lives in HBM throughout.
+`--random-actions` replaces the policy by pre-generated clip(0.3*N(0,1), -1, 1) actions (the
+protocol of the reference's notebooks/test_rodent.ipynb) and skips the Transition logging.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -30,7 +33,7 @@ ENVS_PER_GPU = 4096
 # algorithmic HBM bytes per env-step of the rollout (state in/out, action,
 # obs, traj, reward/done/metrics/info), and tree-sparse algorithmic flops per env-step.
 B_ALG = 6284.0
-F_ALG = 3.9e6 - 0.68e6  # without the policy forward (not in this timed region)
+F_ALG = 3.9e6 - 0.68e6  # step kernel only (the policy forward is a separate kernel)
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 
@@ -64,6 +67,7 @@ def main() -> None:
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autoreset", action="store_true")
+    ap.add_argument("--random-actions", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,11 +95,58 @@ def main() -> None:
     gen.manual_seed(1234 + rank)  # independent stream per rank: envs shard, nothing crosses the links
     state = env.reset(gen)
     total = args.steps + args.warmup
-    actions = torch.clamp(0.3 * torch.randn((total, B, 30), generator=gen), -1.0, 1.0).to(dev)
+    unroll = 20
+    if args.random_actions:
+        actions = torch.clamp(0.3 * torch.randn((total, B, 30), generator=gen), -1.0, 1.0).to(dev)
+
+        def run(k0, n, timed):
+            nonlocal state
+            for k in range(n):
+                if timed:
+                    base.kernel_events = ev[k]
+                state = env.step(state, actions[k0 + k])
+    else:
+        from vnl_brax_imitation_amd import configs
+        from vnl_brax_imitation_amd.ppo_imitation import acting, ppo_networks, running_statistics
+
+        c = configs.TRAIN_CONFIG
+        nets = ppo_networks.make_intention_ppo_networks(
+            base.traj_size, base.observation_size, base.action_size, preprocess_observations_fn=running_statistics.normalize,
+            intention_latent_size=c["intention_latent_size"], encoder_layer_sizes=c["encoder_layer_sizes"],
+            decoder_layer_sizes=c["decoder_layer_sizes"])
+        flat = nets.policy_network.init(torch.Generator().manual_seed(0)).to(dev)
+        norm = running_statistics.init_state(base.observation_size, device=dev)
+        policy = ppo_networks.make_inference_fn(nets)((norm, flat))
+        assert policy.__name__ == "policy_hip"
+        gdev = torch.Generator(device=dev).manual_seed(99 + rank)
+
+        class _Timed:  # records the (start, end) events of every step-kernel launch of the timed region
+            def __init__(self):
+                self.k = 0
+
+        tm = _Timed()
+        orig_step = base.step
+
+        def step_hook(st_, a_):
+            if tm.k is not None and tm.k < len(ev):
+                base.kernel_events = ev[tm.k]
+                tm.k += 1
+            return orig_step(st_, a_)
+
+        def run(k0, n, timed):
+            nonlocal state
+            tm.k = 0 if timed else None
+            base.step = step_hook if timed else orig_step
+            done = 0
+            while done < n:
+                chunk = min(unroll, n - done)
+                state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=("truncation", "traj"))
+                done += chunk
+            base.step = orig_step
     torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        state = env.step(state, actions[k])
+    ev = []
+    run(0, args.warmup, False)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     base.kernel_events = None
     torch.cuda.synchronize(dev)
@@ -103,9 +154,7 @@ def main() -> None:
         dist.barrier()
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        base.kernel_events = ev[k]  # events recorded right around the step-kernel launch, same stream
-        state = env.step(state, actions[args.warmup + k])
+    run(args.warmup, args.steps, True)
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
@@ -138,8 +187,12 @@ def main() -> None:
             "data": "synthetic actions clip(0.3*N(0,1),-1,1); reference clip = shipped groom clip re-processed to "
                     "66 bodies; model = compiled rodent.xml (scale 0.9)",
             "config": {
-                "workload": "rodent imitation rollout (RodentTracking.step, 5 substeps, CG 6/6), single groom clip, "
-                            f"{B} envs/GPU, random actions, auto-reset {'off' if args.no_autoreset else 'on'}",
+                "workload": "rodent imitation rollout, single groom clip, "
+                            f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else
+                                                 "intention-policy forward (HIP) -> ") +
+                            "RodentTracking.step (5 substeps, CG 6/6) -> " +
+                            f"auto-reset {'off' if args.no_autoreset else 'on'}" +
+                            ("" if args.random_actions else " -> Transition logging (unroll 20)"),
                 "envs_per_gpu": B,
                 "parallelism": f"env-sharded x{world}, no data-path collective",
             },

@@ -47,21 +47,26 @@ def actor_step(env, env_state: State, policy, key, extra_fields: Sequence[str] =
 
 def generate_unroll(env, env_state: State, policy, key, unroll_length: int,
                     extra_fields: Sequence[str] = ()) -> Tuple[State, Transition]:
-    """acting.py:60-80: Transitions stacked on a leading time axis [T, B, ...].
+    """acting.py:60-80: Transitions stacked on a leading time axis [T, B, ...], written row by row into
+    buffers allocated once per call (the env mutates its State in place).
     NB (reference behaviour): state_extras['traj'] is nstate.info['traj'], i.e. the reference
     trajectory features AFTER the step (acting.py:49), not the ones the policy saw."""
-    rows = []
-    for _ in range(unroll_length):
+    data: Optional[Transition] = None
+    for t in range(unroll_length):
         env_state, tr = actor_step(env, env_state, policy, key, extra_fields=extra_fields)
-        rows.append(tr.map(lambda x: x.clone()))
-    stack = lambda *xs: torch.stack(xs, dim=0)  # noqa: E731
-    data = Transition(
-        observation=stack(*[r.observation for r in rows]), action=stack(*[r.action for r in rows]),
-        reward=stack(*[r.reward for r in rows]), discount=stack(*[r.discount for r in rows]),
-        next_observation=stack(*[r.next_observation for r in rows]),
-        extras={g: {k: stack(*[r.extras[g][k] for r in rows]) for k in rows[0].extras[g]} for g in rows[0].extras},
-    )
+        if data is None:
+            alloc = lambda x: torch.empty((unroll_length, *x.shape), dtype=x.dtype, device=x.device)  # noqa: E731
+            data = tr.map(alloc)
+        for dst, src in zip(_leaves(data), _leaves(tr)):
+            dst[t].copy_(src)
     return env_state, data
+
+
+def _leaves(tr: Transition):
+    out = [tr.observation, tr.action, tr.reward, tr.discount, tr.next_observation]
+    for g in sorted(tr.extras):
+        out += [tr.extras[g][k] for k in sorted(tr.extras[g])]
+    return out
 
 
 class Evaluator:
