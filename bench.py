@@ -34,6 +34,10 @@ ENVS_PER_GPU = 4096
 # obs, traj, reward/done/metrics/info), and tree-sparse algorithmic flops per env-step.
 B_ALG = 6284.0
 F_ALG = 3.9e6 - 0.68e6  # step kernel only (the policy forward is a separate kernel)
+# HBM bytes per step-kernel launch from the PMC counters (profiles/r01c_full_path_summary.md: separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command, 4096 envs): 10,777 KB fetched
+# (x2 gfx950 read correction = 21.6 MB, an upper bound for 4-B/lane accesses) + 32.0 MB written.
+TRAFFIC_PMC_BYTES_4096 = 21.6e6 + 32.0e6
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 
@@ -184,8 +188,10 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic actions clip(0.3*N(0,1),-1,1); reference clip = shipped groom clip re-processed to "
-                    "66 bodies; model = compiled rodent.xml (scale 0.9)",
+            "data": ("synthetic: " + ("random actions clip(0.3*N(0,1),-1,1)" if args.random_actions else
+                                      "freshly initialised intention network (seed 0)") +
+                     "; reference clip = the shipped groom clip re-processed to 66 bodies; model = compiled rodent.xml "
+                     "(scale 0.9); start frames / reset noise from torch Philox"),
             "config": {
                 "workload": "rodent imitation rollout, single groom clip, "
                             f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else
@@ -203,7 +209,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": TRAFFIC_PMC_BYTES_4096 if B == 4096 else None,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": B_ALG * B,
                 "note": "the fused step is FP32-VALU/latency bound, not HBM bound (SURVEY 8d); valu_frac is the "
