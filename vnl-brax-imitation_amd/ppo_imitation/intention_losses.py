@@ -23,6 +23,14 @@ def kl_divergence(mean: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
     return -0.5 * torch.mean(1 + logvar - mean.square() - logvar.exp())
 
 
+def _corrcoef(x: torch.Tensor) -> torch.Tensor:
+    """jnp.corrcoef of the rows of x (torch.corrcoef reads back to the host, which a hipGraph capture forbids)."""
+    xm = x - x.mean(dim=1, keepdim=True)
+    c = xm @ xm.T / (x.shape[1] - 1)
+    d = torch.sqrt(torch.diagonal(c))
+    return (c / (d[:, None] * d[None, :])).clamp(-1.0, 1.0)
+
+
 def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_: float = 1.0,
                 discount: float = 0.99):
     """intention_losses.py:26-87; inputs time-major [T, B]; returns (vs, advantages), no gradient."""
@@ -108,7 +116,7 @@ def compute_ppo_intention_loss(
     with torch.no_grad():
         explained_variance = 1.0 - (v_loss / rewards.var(unbiased=False))
         # jnp.corrcoef(vs, rewards) is a (2T x 2T) matrix that the trainer later averages (:189, C.14)
-        prediction_corr = torch.corrcoef(torch.cat([vs, rewards], dim=0)).mean() if T * 2 <= 256 else torch.zeros(())
+        prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if T * 2 <= 256 else torch.zeros((), device=dev)
     return total_loss, {
         "total_loss": total_loss.detach(),
         "policy_loss": policy_loss.detach(),

@@ -49,17 +49,19 @@ class FlatAdam:
 
     def init(self, params: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {"mu": torch.zeros_like(params), "nu": torch.zeros_like(params),
-                "count": torch.zeros((), dtype=torch.int64)}
+                "count": torch.zeros((), dtype=torch.int64, device=params.device)}
 
     @torch.no_grad()
     def update(self, grads: torch.Tensor, state: Dict[str, torch.Tensor], params: torch.Tensor) -> None:
+        """No host read-back (the step count stays on the device), so the update can sit inside a hipGraph."""
         state["count"] += 1
-        t = int(state["count"])
+        t = state["count"].to(torch.float64)
+        bc1 = (1 - torch.pow(torch.full_like(t, self.b1), t)).to(params.dtype)
+        bc2 = (1 - torch.pow(torch.full_like(t, self.b2), t)).to(params.dtype)
         state["mu"].mul_(self.b1).add_(grads, alpha=1 - self.b1)
         state["nu"].mul_(self.b2).addcmul_(grads, grads, value=1 - self.b2)
-        bc1, bc2 = 1 - self.b1 ** t, 1 - self.b2 ** t
         denom = (state["nu"] / bc2).sqrt_().add_(self.eps)
-        params.addcdiv_(state["mu"], denom, value=-self.lr / bc1)
+        params.sub_((state["mu"] / bc1).div_(denom).mul_(self.lr))
 
 
 def _dist_info():
@@ -101,12 +103,17 @@ def train(
     randomization_fn=None,
     kl_weight: float = 1e-4,
     reset_info_on_autoreset: bool = False,
+    capture_graph: Optional[bool] = None,
 ):
     """PPO training (train.py:62-491).
 
     `num_envs`, `batch_size` are GLOBAL counts as in the reference (train.py:128-129 scales them by
     the device count); each rank owns `num_envs // world` envs -- `environment.num_envs` must equal
     that -- and `batch_size // world` trajectories per minibatch.
+
+    `capture_graph` (default: on for HIP devices): the minibatch step (gather -> loss -> backward
+    [-> Adam when single-GPU]) is captured once into a hipGraph and replayed -- the eager step is
+    ~500 launches of microsecond kernels and purely launch-bound.
     """
     dist, rank, world = _dist_info()
     assert batch_size * num_minibatches % num_envs == 0
@@ -146,7 +153,7 @@ def train(
     flat.requires_grad_(True)
     optimizer = FlatAdam(learning_rate)
     training_state = TrainingState(
-        optimizer_state={k: v.to(device) if v.dim() else v for k, v in optimizer.init(flat.detach()).items()},
+        optimizer_state=optimizer.init(flat.detach()),
         params=flat,
         normalizer_params=running_statistics.init_state(env_state.obs.shape[-1], device=device),
         env_steps=0,
@@ -172,8 +179,80 @@ def train(
         optimizer.update(p.grad, training_state.optimizer_state, p.data)
         return metrics
 
+    if capture_graph is None:
+        capture_graph = device.type == "cuda"
+    graphed: Dict[str, Any] = {}
+
+    def build_graphed(data: acting.Transition, normalizer_params) -> None:
+        """Static buffers + one captured minibatch step.  Inputs of a replay: `full` (the whole batch),
+        `idx` (this minibatch's rows), `norm`, `noise`; outputs: the parameter update and `acc`."""
+        n, T = data.reward.shape[:2]
+        mb = n // num_minibatches
+        g = graphed
+        g["full"] = data.map(torch.clone)
+        g["idx"] = torch.zeros(mb, dtype=torch.int64, device=device)
+        g["norm"] = normalizer_params.clone()
+        g["noise"] = {"latent": torch.zeros(T, mb, ppo_network.policy_module.latents, device=device),
+                      "entropy": torch.zeros(T, mb, ppo_network.parametric_action_distribution.event_size,
+                                             device=device)}
+        p = training_state.params
+        saved = (p.detach().clone(), {k: v.clone() for k, v in training_state.optimizer_state.items()})
+
+        def body():
+            full, idx = g["full"], g["idx"]
+            mbd = acting.Transition(
+                full.observation.index_select(0, idx), full.action.index_select(0, idx),
+                full.reward.index_select(0, idx), full.discount.index_select(0, idx),
+                full.next_observation[:, -1:].index_select(0, idx),  # only the bootstrap row is read
+                {k: {kk: vv.index_select(0, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
+            loss, metrics = loss_fn(split(p), g["norm"], mbd, None, noise=g["noise"])
+            loss.backward()
+            if dist is None:
+                optimizer.update(p.grad, training_state.optimizer_state, p.data)
+            return metrics
+
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm-up off the capture stream (library handles, autograd buffers)
+                p.grad = None
+                m = body()
+        torch.cuda.current_stream(device).wait_stream(side)
+        g["keys"] = sorted(m.keys())
+        g["acc"] = torch.zeros(len(g["keys"]), device=device)
+        p.grad = None
+        g["graph"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["graph"]):
+            m = body()
+            g["acc"] += torch.stack([m[k].to(torch.float32).reshape(()) for k in g["keys"]])
+        with torch.no_grad():  # the warm-up iterations must not count as training
+            p.data.copy_(saved[0])
+            for k, v in saved[1].items():
+                training_state.optimizer_state[k].copy_(v)
+
+    def sgd_step_graphed(data: acting.Transition, normalizer_params) -> Metrics:
+        g = graphed
+        n = data.reward.shape[0]
+        mb = n // num_minibatches
+        perm = torch.randperm(n, generator=g_env).to(device)
+        g["acc"].zero_()
+        for i in range(num_minibatches):
+            g["idx"].copy_(perm[i * mb:(i + 1) * mb])
+            for name in ("latent", "entropy"):  # same draws, same order as the eager loss
+                torch.randn(g["noise"][name].shape, generator=g_dev, device=device, out=g["noise"][name])
+            g["graph"].replay()
+            if dist is not None:
+                p = training_state.params
+                dist.all_reduce(p.grad)  # C1
+                p.grad.div_(world)
+                optimizer.update(p.grad, training_state.optimizer_state, p.data)
+        acc = g["acc"] / num_minibatches
+        return {k: acc[i] for i, k in enumerate(g["keys"])}
+
     def sgd_step(data: acting.Transition, normalizer_params) -> Metrics:
         """train.py:270-291: one shared permutation, num_minibatches steps."""
+        if capture_graph:
+            return sgd_step_graphed(data, normalizer_params)
         n = data.reward.shape[0]
         perm = torch.randperm(n, generator=g_env).to(device)
         acc: Dict[str, torch.Tensor] = {}
@@ -209,6 +288,13 @@ def train(
         assert data.discount.shape[1:] == (unroll_length,)
         normalizer_params = running_statistics.update(training_state.normalizer_params, data.observation,
                                                       distributed=dist is not None)  # C2
+        if capture_graph:
+            if not graphed:
+                build_graphed(data, normalizer_params)
+            for dst, src in zip(acting._leaves(graphed["full"]), acting._leaves(data)):
+                dst.copy_(src)
+            for f in ("count", "mean", "summed_variance", "std"):
+                getattr(graphed["norm"], f).copy_(getattr(normalizer_params, f))
         acc: Dict[str, torch.Tensor] = {}
         for _ in range(num_updates_per_batch):
             m = sgd_step(data, normalizer_params)
