@@ -42,6 +42,8 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_ROWS_PER_LANE 512
 #define VNL_ROWS_SMALL 320
 #define VNL_PREFIX_PER_LANE 512
+#define VNL_ROWSETS_1 64
+#define VNL_ROWSETS_2 128
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)
 #define VNL_SYNC()

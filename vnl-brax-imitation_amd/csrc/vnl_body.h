@@ -43,6 +43,8 @@
 #define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
 #define VNL_ROWS_SMALL 5    /* specialisation for nefc <= 320 (the rodent has 303) */
 #define VNL_PREFIX_PER_LANE 8 /* 6 * nbody <= 512 elements per in-place tree prefix */
+#define VNL_ROWSETS_1 1 /* matrix rows a lane keeps in registers while factorising: nv <= 64 .. */
+#define VNL_ROWSETS_2 2 /* .. or nv <= 128 */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
 #define VNL_SERIAL if (lane == 0)
 #define VNL_SYNC() __syncthreads()
@@ -428,7 +430,7 @@ struct EnvWave {
   // iteration k run in one parallel region; pair p -> (a, a+c) comes from one universal triangular
   // table (ordered by a+c, so a prefix of it enumerates any depth).  The division of row k by its
   // pivot is deferred to one final pass (row k is never touched again after iteration k).
-  VNL_HD void factor() const {
+  VNL_HD void factor_lds() const {
     // (A column-per-lane variant that keeps the pivot row in registers and broadcasts it with
     // v_readlane was measured 2x slower: one LDS round trip in flight per step.  What matters is the
     // number of independent LDS accesses in flight, so each lane streams one ancestor row, 8-wide.)
@@ -473,7 +475,7 @@ struct EnvWave {
   // the rows of one depth level only need already-converted ancestor rows and their own (still L)
   // row.  Per level: (A) stage the row base addresses of the ancestors, (B) all entries of the level
   // in parallel into a staging buffer, (C) write back.
-  VNL_HD void invert_factor() const {
+  VNL_HD void invert_factor_lds() const {
     int stage = L.Ma;              // Ma|grad free while factorising
     int* base = (int*)(s + L.Mgrad);  // Mgrad|search likewise
     for (int lev = 1; lev <= m.max_depth; lev++) {
@@ -516,6 +518,153 @@ struct EnvWave {
       }
       VNL_SYNC();
     }
+  }
+
+  // ---- factor / inversion with the matrix rows in registers --------------------------------------
+  // Lane l keeps rows l, l+64, .. of the tree-sparse matrix in registers: entry c of a row is its
+  // column at absolute depth c on the row's ancestor path (c < depth), the diagonal apart.  Static
+  // register indices need static c, hence the MAXD template (max_depth < MAXD) and full unrolling.
+  struct R4 {
+    vreal x, y, z, w;
+  };
+  VNL_HD static R4 ld4a(const vreal* p) {  // p is 16-byte aligned in the float build
+#if defined(__HIPCC__)
+    if constexpr (sizeof(vreal) == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 v = *(const f4*)p;
+      return R4{v.x, v.y, v.z, v.w};
+    }
+#endif
+    return R4{p[0], p[1], p[2], p[3]};
+  }
+  VNL_HD static void st4a(vreal* p, vreal x, vreal y, vreal z, vreal w) {
+#if defined(__HIPCC__)
+    if constexpr (sizeof(vreal) == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 v = {(float)x, (float)y, (float)z, (float)w};
+      *(f4*)p = v;
+      return;
+    }
+#endif
+    p[0] = x, p[1] = y, p[2] = z, p[3] = w;
+  }
+
+  // In-place L'DL (mj_factorM order, pivots nv-1 .. 0).  Step j: the lane that owns row j publishes
+  // it (numerators + pivot) in an LDS scratch line; every proper ancestor row a of j then does
+  // row_a[c] -= (row_j[a] / D_j) * row_j[c] on its registers, reading row_j as LDS broadcasts.  One
+  // wave executes its LDS operations in order, so the scratch line needs no double buffering.
+  template <int NSET, int MAXD>
+  VNL_HD void factor_rows() const {
+    vreal rr[NSET][MAXD], dg[NSET];
+    int dep[NSET], last[NSET];
+    const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; needs MAXD + 8 floats
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      int a = (int)lane + q * VNL_LANES;
+      bool ok = a < m.nv;
+      int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
+      dep[q] = d, last[q] = ok ? a + m.dof_ndesc[a] : -1;
+      dg[q] = ok ? s[L.LD + adr] : vreal(1.);
+#pragma unroll
+      for (int c = 0; c < MAXD; c++) rr[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
+    }
+    VNL_SERIAL { s[sc + MAXD + 4] = vreal(0.); }  // what lanes that are no ancestor of j read as "row_j[a]"
+    VNL_SYNC();
+    for (int j = m.nv - 1; j >= 0; j--) {
+      const int qj = j / VNL_LANES, lj = j - qj * VNL_LANES, dj = depth(j);
+#pragma unroll
+      for (int q = 0; q < NSET; q++) {
+        if (q == qj && (int)lane == lj) {
+#pragma unroll
+          for (int c = 0; c < MAXD; c += 4)
+            if (c < dj) st4a(s + sc + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
+          s[sc + MAXD] = dg[q];
+        }
+      }
+      VNL_SYNC();
+      const vreal inv = vreal(1.) / s[sc + MAXD];
+      VNL_SERIAL { s[L.dinv + j] = inv; }
+#pragma unroll
+      for (int q = 0; q < NSET; q++) {
+        if (q <= qj && dj > 0) {  // rows above j cannot be its ancestors
+          int a = (int)lane + q * VNL_LANES;
+          bool anc = a < j && j <= last[q];
+          vreal traw = s[sc + (anc ? dep[q] : MAXD + 4)];
+          vreal t = traw * inv;
+#pragma unroll
+          for (int c = 0; c < MAXD; c += 4) {
+            if (c < dj) {
+              R4 x = ld4a(s + sc + c);
+              rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+            }
+          }
+          dg[q] -= t * traw;
+        }
+      }
+    }
+    VNL_SYNC();
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      int a = (int)lane + q * VNL_LANES;
+      if (a < m.nv) {
+        int adr = madr(a), d = dep[q];
+        vreal di = s[L.dinv + a];
+        s[L.LD + adr] = dg[q];
+#pragma unroll
+        for (int c = 0; c < MAXD; c++)
+          if (c < d) s[L.LD + adr + d - c] = rr[q][c] * di;
+      }
+    }
+    VNL_SYNC();
+  }
+
+  // L -> L^-1 in place from N L = I:  N(i,t) = -L(i,t) - sum_{0<u<t} N(i,u) L(anc_u(i), t-u).  Row i of
+  // N only needs its own earlier entries (registers) and the ORIGINAL rows of its ancestors, so all
+  // rows run at once without levels; the results are written back after one barrier.
+  template <int NSET, int MAXD>
+  VNL_HD void invert_rows() const {
+    // Sets are taken from the last to the first and written back one at a time: rows of a later
+    // set are never ancestors of rows of an earlier one.
+#pragma unroll
+    for (int q = NSET - 1; q >= 0; q--) {
+      vreal nn[MAXD];
+      int a = (int)lane + q * VNL_LANES;
+      bool ok = a < m.nv;
+      int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
+      int own = L.LD + adr;
+      int pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
+#pragma unroll
+      for (int u = 1; u < MAXD; u++) pb[u] = L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
+#pragma unroll
+      for (int t = 1; t < MAXD; t++) {
+        if (vnl_wave_any(t <= d)) {
+          vreal acc = t <= d ? -s[own + t] : vreal(0.);
+#pragma unroll
+          for (int u = 1; u < t; u++) acc -= nn[u] * s[pb[u] + (t - u)];
+          nn[t] = acc;
+        }
+      }
+      VNL_SYNC();
+#pragma unroll
+      for (int t = 1; t < MAXD; t++)
+        if (t <= d) s[own + t] = nn[t];
+      VNL_SYNC();
+    }
+  }
+
+  VNL_HD void factor() const {
+    const int nv = m.nv, md = m.max_depth;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_rows<VNL_ROWSETS_1, 16>();
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) factor_rows<VNL_ROWSETS_1, 36>();
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36) factor_rows<VNL_ROWSETS_2, 36>();
+    else factor_lds();
+  }
+  VNL_HD void invert_factor() const {
+    const int nv = m.nv, md = m.max_depth;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_rows<VNL_ROWSETS_1, 16>();
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_1, 36>();
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_2, 36>();
+    else invert_factor_lds();
   }
 
   // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
