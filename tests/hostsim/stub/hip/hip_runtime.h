@@ -54,6 +54,10 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_AT(name, j) name[j]
 #define VNL_GETF(name, a) name[a]
 #define VNL_GETI(name, a) name[a]
+#define VNL_ROWGETI(name, q, l) name[q]
+#define VNL_ROWGETF(expr, q, l) (expr)
+#define VNL_WAVE_FENCE()
+#define vnl_recip(x) (vreal(1.) / (x))
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
   do {                                                                         \
     dim3 g_ = (grid), b_ = (block);                                            \

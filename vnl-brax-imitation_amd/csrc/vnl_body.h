@@ -69,6 +69,16 @@ VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
 #define VNL_AT(name, j) name
 #define VNL_GETF(name, a) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, name), a))
 #define VNL_GETI(name, a) __builtin_amdgcn_readlane(name, a)
+// value that lane l holds for its q-th item (rows are dealt out as item = lane + 64 q)
+#define VNL_ROWGETI(name, q, l) __builtin_amdgcn_readlane(name[q], l)
+#define VNL_ROWGETF(expr, q, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, expr), l))
+// orders the LDS accesses of the lanes of ONE wave (its LDS operations execute in issue order): no instruction
+#define VNL_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+// 1/x: v_rcp_f32 (1 ulp) + one Newton step instead of the ~10-instruction IEEE division
+VNL_HD float vnl_recip(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return r * (2.0f - x * r);
+}
 #endif
 
 // Diagnostic build only (-DVNL_PROFILE, csrc/build.py --profile): per-stage s_memtime stamps summed
@@ -555,6 +565,8 @@ struct EnvWave {
   // wave executes its LDS operations in order, so the scratch line needs no double buffering.
   template <int NSET, int MAXD>
   VNL_HD void factor_rows() const {
+    static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
+    constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
     vreal rr[NSET][MAXD], dg[NSET];
     int dep[NSET], last[NSET];
     const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; needs MAXD + 8 floats
@@ -571,31 +583,44 @@ struct EnvWave {
     VNL_SERIAL { s[sc + MAXD + 4] = vreal(0.); }  // what lanes that are no ancestor of j read as "row_j[a]"
     VNL_SYNC();
     for (int j = m.nv - 1; j >= 0; j--) {
-      const int qj = j / VNL_LANES, lj = j - qj * VNL_LANES, dj = depth(j);
+      const int qj = j / VNL_LANES, lj = j - qj * VNL_LANES;
+      int dj = 0;
+      vreal inv = vreal(0.);
 #pragma unroll
       for (int q = 0; q < NSET; q++) {
-        if (q == qj && (int)lane == lj) {
+        if (q == qj) {
+          dj = VNL_ROWGETI(dep, q, lj);
+          vreal mine = vnl_recip(dg[q]);
+          inv = VNL_ROWGETF(mine, q, lj);
+          if ((int)lane == lj) {  // row j goes to LDS only so that each ancestor a can pick row_j[a]
+            s[L.dinv + j] = mine;
 #pragma unroll
-          for (int c = 0; c < MAXD; c += 4)
-            if (c < dj) st4a(s + sc + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
-          s[sc + MAXD] = dg[q];
+            for (int c0 = 0; c0 < MAXD; c0 += CH) {
+              if (c0 < dj) {
+#pragma unroll
+                for (int c = c0; c < c0 + CH; c += 4) st4a(s + sc + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
+              }
+            }
+          }
         }
       }
-      VNL_SYNC();
-      const vreal inv = vreal(1.) / s[sc + MAXD];
-      VNL_SERIAL { s[L.dinv + j] = inv; }
+      if (dj == 0) continue;
+      VNL_WAVE_FENCE();
+      // row_a[c] -= (row_j[a] / D_j) * row_j[c]: only the lanes that own an ancestor row of j take part
 #pragma unroll
       for (int q = 0; q < NSET; q++) {
-        if (q <= qj && dj > 0) {  // rows above j cannot be its ancestors
-          int a = (int)lane + q * VNL_LANES;
-          bool anc = a < j && j <= last[q];
-          vreal traw = s[sc + (anc ? dep[q] : MAXD + 4)];
+        int a = (int)lane + q * VNL_LANES;
+        if (q <= qj && a < j && j <= last[q]) {  // rows above j cannot be its ancestors
+          vreal traw = s[sc + dep[q]];
           vreal t = traw * inv;
 #pragma unroll
-          for (int c = 0; c < MAXD; c += 4) {
-            if (c < dj) {
-              R4 x = ld4a(s + sc + c);
-              rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+          for (int c0 = 0; c0 < MAXD; c0 += CH) {
+            if (c0 < dep[q]) {
+#pragma unroll
+              for (int c = c0; c < c0 + CH; c += 4) {
+                R4 x = ld4a(s + sc + c);
+                rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+              }
             }
           }
           dg[q] -= t * traw;
@@ -632,15 +657,18 @@ struct EnvWave {
       bool ok = a < m.nv;
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
       int own = L.LD + adr;
-      int pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
+      const vreal* pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
 #pragma unroll
-      for (int u = 1; u < MAXD; u++) pb[u] = L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
+      for (int u = 1; u < MAXD; u++) pb[u] = s + L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
 #pragma unroll
       for (int t = 1; t < MAXD; t++) {
         if (vnl_wave_any(t <= d)) {
+          vreal x[MAXD];  // all operands of entry t are fetched before the (dependent) multiply-add chain
+#pragma unroll
+          for (int u = 1; u < t; u++) x[u] = pb[u][t - u];
           vreal acc = t <= d ? -s[own + t] : vreal(0.);
 #pragma unroll
-          for (int u = 1; u < t; u++) acc -= nn[u] * s[pb[u] + (t - u)];
+          for (int u = 1; u < t; u++) acc -= nn[u] * x[u];
           nn[t] = acc;
         }
       }
@@ -1279,6 +1307,23 @@ struct EnvWave {
         ls_load(rows);
         ls_eval<3>(rows, a3, vreal(0.), vreal(0.), vreal(0.), p);
         if (p[0].cost == vreal(-1.)) s[L.tmp] = p[1].cost;  // keep the result alive
+      } else if (m.dbg_stage == 9) {
+        make_constraint(cvel);
+      } else if (m.dbg_stage == 10) {
+        vreal c = constraint_force();
+        if (c == vreal(-1.)) s[L.tmp] = c;
+      } else if (m.dbg_stage == 11) {
+        smooth_forces();
+      } else if (m.dbg_stage == 12) {
+        vreal c = vdot(L.smooth, L.qacc_smooth) + vdot(L.qacc, L.smooth) + vdot(L.qacc, L.qacc) + vdot(L.smooth, L.smooth);
+        if (c == vreal(-1.)) s[L.tmp] = c;
+      } else if (m.dbg_stage == 13) {
+        LsRows<VNL_ROWS_SMALL> rows;
+        ls_load(rows);
+        vreal a1[1] = {vreal(1e-4)};
+        LsPoint p;
+        ls_eval<1>(rows, a1, vreal(0.), vreal(0.), vreal(0.), &p);
+        if (p.cost == vreal(-1.)) s[L.tmp] = p.cost;
       }
     }
     solve();
