@@ -19,7 +19,7 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
           (["-DVNL_PROFILE"] if profile else []) + [os.path.join(HERE, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

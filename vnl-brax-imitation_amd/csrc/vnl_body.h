@@ -74,6 +74,14 @@ VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
 #define VNL_ROWGETF(expr, q, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, expr), l))
 // orders the LDS accesses of the lanes of ONE wave (its LDS operations execute in issue order): no instruction
 #define VNL_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+// out[k] = (int)base[k * stride] for k < VNL_FAC_LINES: lane k loads, v_readlane broadcasts
+#define VNL_LINE_HEADERS(out, base, stride)                                                       \
+  do {                                                                                            \
+    int hv_ = (int)(base)[((int)lane < VNL_FAC_LINES ? (int)lane : VNL_FAC_LINES - 1) * (stride)]; \
+    _Pragma("unroll") for (int k_ = 0; k_ < VNL_FAC_LINES; k_++) out[k_] = __builtin_amdgcn_readlane(hv_, k_); \
+  } while (0)
+#define VNL_COUNT(pred) __popcll(__ballot(pred))                  /* lanes (items) for which pred holds */
+#define VNL_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)        /* a value known to be the same in every lane */
 // 1/x: v_rcp_f32 (1 ulp) + one Newton step instead of the ~10-instruction IEEE division
 VNL_HD float vnl_recip(float x) {
   float r = __builtin_amdgcn_rcpf(x);
@@ -564,12 +572,12 @@ struct EnvWave {
   // row_a[c] -= (row_j[a] / D_j) * row_j[c] on its registers, reading row_j as LDS broadcasts.  One
   // wave executes its LDS operations in order, so the scratch line needs no double buffering.
   template <int NSET, int MAXD>
-  VNL_HD void factor_rows() const {
+  VNL_HD void factor_rows(bool with_loop = true) const {
     static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
     constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
     vreal rr[NSET][MAXD], dg[NSET];
     int dep[NSET], last[NSET];
-    const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; needs MAXD + 8 floats
+    const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; VNL_FAC_LINES * (MAXD + 4) floats
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
@@ -580,52 +588,87 @@ struct EnvWave {
 #pragma unroll
       for (int c = 0; c < MAXD; c++) rr[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
     }
-    VNL_SERIAL { s[sc + MAXD + 4] = vreal(0.); }  // what lanes that are no ancestor of j read as "row_j[a]"
+    // Schedule (host, build_dev_model): row j is the pivot of step dof_ftime[j], after all of its
+    // descendants; rows with disjoint subtrees share a step, each with its own scratch line
+    // [row numerators (MAXD) | 1/pivot | j | pad], so the chain of dependent steps is the tree height.
+    constexpr int LW = MAXD + 4;
+    int ftime[NSET], fslot[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      int a = (int)lane + q * VNL_LANES;
+      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1, fslot[q] = a < m.nv ? m.dof_fslot[a] : 0;
+    }
     VNL_SYNC();
-    for (int j = m.nv - 1; j >= 0; j--) {
-      const int qj = j / VNL_LANES, lj = j - qj * VNL_LANES;
-      int dj = 0;
-      vreal inv = vreal(0.);
+    const int nsteps = with_loop ? m.fac_steps : 0;  // (false: diagnostic pricing of the load / store phases only)
+    for (int step = 0; step < nsteps; step++) {
+      int npub = 0;
 #pragma unroll
       for (int q = 0; q < NSET; q++) {
-        if (q == qj) {
-          dj = VNL_ROWGETI(dep, q, lj);
-          vreal mine = vnl_recip(dg[q]);
-          inv = VNL_ROWGETF(mine, q, lj);
-          if ((int)lane == lj) {  // row j goes to LDS only so that each ancestor a can pick row_j[a]
-            s[L.dinv + j] = mine;
-#pragma unroll
-            for (int c0 = 0; c0 < MAXD; c0 += CH) {
-              if (c0 < dj) {
-#pragma unroll
-                for (int c = c0; c < c0 + CH; c += 4) st4a(s + sc + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
-              }
-            }
-          }
-        }
-      }
-      if (dj == 0) continue;
-      VNL_WAVE_FENCE();
-      // row_a[c] -= (row_j[a] / D_j) * row_j[c]: only the lanes that own an ancestor row of j take part
-#pragma unroll
-      for (int q = 0; q < NSET; q++) {
-        int a = (int)lane + q * VNL_LANES;
-        if (q <= qj && a < j && j <= last[q]) {  // rows above j cannot be its ancestors
-          vreal traw = s[sc + dep[q]];
-          vreal t = traw * inv;
+        bool mine = ftime[q] == step;
+        npub += VNL_COUNT(mine);
+        if (mine) {
+          int line = sc + fslot[q] * LW, a = (int)lane + q * VNL_LANES;
 #pragma unroll
           for (int c0 = 0; c0 < MAXD; c0 += CH) {
             if (c0 < dep[q]) {
 #pragma unroll
-              for (int c = c0; c < c0 + CH; c += 4) {
-                R4 x = ld4a(s + sc + c);
-                rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
-              }
+              for (int c = c0; c < c0 + CH; c += 4) st4a(s + line + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
             }
           }
-          dg[q] -= t * traw;
+          vreal inv = vnl_recip(dg[q]);
+          s[line + MAXD] = inv;
+          s[line + MAXD + 1] = vreal(a);  // exact: a < 2^24
+          s[L.dinv + a] = inv;
         }
       }
+      VNL_WAVE_FENCE();
+      // row_a[c] -= (row_j[a] / D_j) * row_j[c] for every published j that row a is an ancestor of.
+      // Rows inside a chain have exactly one such j per step and take it in the first pass, all chains
+      // at once (each lane reads ITS line); only rows above a branching point need further passes.
+      unsigned match[NSET];
+#pragma unroll
+      for (int q = 0; q < NSET; q++) match[q] = 0u;
+      int jk[VNL_FAC_LINES];  // pivot rows of this step: ONE wave-wide read of the line headers, then broadcasts
+      VNL_LINE_HEADERS(jk, s + sc + MAXD + 1, LW);
+#pragma unroll
+      for (int k = 0; k < VNL_FAC_LINES; k++) {
+        if (k < npub) {
+          const int j = jk[k];
+#pragma unroll
+          for (int q = 0; q < NSET; q++) {
+            int a = (int)lane + q * VNL_LANES;
+            match[q] |= (a < j && j <= last[q]) ? (1u << k) : 0u;
+          }
+        }
+      }
+      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
+        bool more = false;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) more = more || match[q] != 0u;
+        if (!vnl_wave_any(more)) break;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) {
+          if (match[q] != 0u) {
+            const int k = __builtin_ctz(match[q]);
+            match[q] &= match[q] - 1u;
+            const vreal* line = s + sc + k * LW;
+            vreal traw = line[dep[q]];
+            vreal t = traw * line[MAXD];
+#pragma unroll
+            for (int c0 = 0; c0 < MAXD; c0 += CH) {
+              if (c0 < dep[q]) {
+#pragma unroll
+                for (int c = c0; c < c0 + CH; c += 4) {
+                  R4 x = ld4a(line + c);
+                  rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+                }
+              }
+            }
+            dg[q] -= t * traw;
+          }
+        }
+      }
+      VNL_WAVE_FENCE();
     }
     VNL_SYNC();
 #pragma unroll
@@ -680,11 +723,13 @@ struct EnvWave {
     }
   }
 
-  VNL_HD void factor() const {
+  VNL_HD void factor(bool with_loop = true) const {
     const int nv = m.nv, md = m.max_depth;
-    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_rows<VNL_ROWSETS_1, 16>();
-    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) factor_rows<VNL_ROWSETS_1, 36>();
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36) factor_rows<VNL_ROWSETS_2, 36>();
+    // the scratch lines of factor_rows live in the four dead CG vectors (Ma .. search)
+    const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16>(with_loop);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36>(with_loop);
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_2, 36>(with_loop);
     else factor_lds();
   }
   VNL_HD void invert_factor() const {
@@ -1276,6 +1321,11 @@ struct EnvWave {
         kinematics();
         body_inertias(true);
         (void)bias_forces();
+      } else if (m.dbg_stage == 14) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+        factor(false);
       }
     }
     kinematics();

@@ -323,6 +323,25 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     }
     UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc) UPI(M_row, row)
     UPI(dof_ndesc, ndesc) UPI(dof_limrow, limrow)
+    // Factorisation schedule: row j can be the pivot once all its descendants have been; rows whose
+    // subtrees are disjoint go in the same step (at most VNL_FAC_LINES of them, one scratch line each).
+    std::vector<int> ftime(nv, 0), fslot(nv, 0), count;
+    for (int j = nv - 1; j >= 0; j--) {  // children have larger indices: their times are final here
+      int t = 0;
+      for (int i = j + 1; i <= j + ndesc[j]; i++)
+        if (par[i] == j) t = ftime[i] + 1 > t ? ftime[i] + 1 : t;
+      while ((int)count.size() <= t) count.push_back(0);
+      while (count[t] >= VNL_FAC_LINES) {
+        t++;
+        if ((int)count.size() <= t) count.push_back(0);
+      }
+      ftime[j] = t, fslot[j] = count[t]++;
+    }
+    // a parent must come strictly after each child even when the child was pushed to a later step
+    for (int j = nv - 1; j >= 0; j--)
+      if (par[j] >= 0 && ftime[par[j]] <= ftime[j]) return fail(VNL_ERR_UNSUPPORTED, "factorisation schedule is not causal");
+    d.fac_steps = (int)count.size();
+    UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))

@@ -16,9 +16,12 @@ typedef VNL_REAL vreal;
 #define VNL_GEOM_CAPSULE 3
 #define VNL_GEOM_ELLIPSOID 4
 
+#define VNL_FAC_LINES 6 /* pivots per factorisation step (scratch lines in the dead CG vectors) */
+
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
   int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
+  int fac_steps; /* number of steps of the factorisation schedule */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
@@ -39,6 +42,7 @@ struct DevModel {
   // dofs; tree-sparse qM layout (MuJoCo dof_Madr order: self, parent, grandparent, ...)
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
+  const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot, and its scratch line */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
   const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
   const vreal *dof_armature, *dof_damping;
