@@ -162,6 +162,34 @@ int vnl_policy_forward(vnl_policy*, const float* params, const float* obs_mean, 
                        int32_t batch, int32_t deterministic, float* action, float* raw_action, float* log_prob,
                        float* logits, float* latent_mean, float* latent_logvar, void* stream);
 
+/* ---- rollout post-processing: the training wrappers and the Transition logging in ONE launch ----
+ * brax EpisodeWrapper + AutoResetWrapper as applied by the reference's wrap_for_training
+ * (ppo_imitation/train.py:204-214) and the per-step Transition of actor_step
+ * (ppo_imitation/acting.py:34-57).  Per env e, in this order:
+ *   steps = (prev_done ? 0 : steps) + action_repeat;  over = steps >= episode_length
+ *   truncation = over ? 1 - done : 0;  done = over ? 1 : done;  prev_done = done
+ *   log_reward = reward;  log_discount = 1 - done;  log_truncation = truncation   (each optional)
+ *   every op:  v = (first && done) ? first[e] : src[e];  dst[e] = v (if dst);  log[e] = v (if log)
+ * All arrays are row-major [num_envs][width] device buffers of 32-bit words (float32; int32 frame
+ * counters are moved bit-exactly).  dst may alias src. */
+#define VNL_POST_MAX_OPS 24
+typedef struct vnl_post_op {
+  float* dst;
+  const float* src;
+  const float* first;
+  float* log;
+  int32_t width;
+  int32_t pad_;
+} vnl_post_op;
+typedef struct vnl_post_desc {
+  float *steps, *prev_done, *done, *truncation;
+  const float* reward;
+  float *log_reward, *log_discount, *log_truncation;
+  int32_t episode_length, action_repeat, num_ops, pad_;
+  vnl_post_op ops[VNL_POST_MAX_OPS];
+} vnl_post_desc;
+int vnl_rollout_post(const vnl_post_desc*, int32_t num_envs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

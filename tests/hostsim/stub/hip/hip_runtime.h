@@ -36,6 +36,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 // Fork-join primitives of csrc/vnl_body.h, host flavour: one pass per workgroup in which every
 // parallel-for region simply runs over all its items, serial regions run once, and cross-lane
 // reductions are the identity (the single pass has already accumulated every item).
+#define __syncthreads()
 #define VNL_FORKJOIN_DEFINED
 #define VNL_HD inline
 #define VNL_LANES 1
@@ -43,6 +44,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_ROWS_SMALL 320
 #define VNL_PREFIX_PER_LANE 512
 #define VNL_ROWSETS_1 64
+#define VNL_POST_THREADS 1
 #define VNL_ROWSETS_2 128
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)

@@ -72,10 +72,25 @@ class PolicySpec(C.Structure):
     ]
 
 
+POST_MAX_OPS = 24
+
+
+class PostOp(C.Structure):  # include/vnl.h: vnl_post_op
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("first", C.c_void_p), ("log", C.c_void_p),
+                ("width", C.c_int32), ("pad_", C.c_int32)]
+
+
+class PostDesc(C.Structure):  # include/vnl.h: vnl_post_desc
+    _fields_ = [(n, C.c_void_p) for n in ("steps", "prev_done", "done", "truncation", "reward", "log_reward",
+                                          "log_discount", "log_truncation")] + \
+               [("episode_length", C.c_int32), ("action_repeat", C.c_int32), ("num_ops", C.c_int32),
+                ("pad_", C.c_int32), ("ops", PostOp * POST_MAX_OPS)]
+
+
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
     "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
-    "vnl_policy_num_params", "vnl_policy_forward",
+    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post",
 )
 
 
@@ -98,6 +113,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_step.argtypes = [vp, vp, C.POINTER(StatePtrs), vp]
     lib.vnl_env_debug.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.vnl_rollout_post.argtypes = [C.POINTER(PostDesc), C.c_int32, vp]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
         lib.vnl_policy_destroy.argtypes = [vp]

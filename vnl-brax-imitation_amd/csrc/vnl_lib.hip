@@ -598,4 +598,56 @@ extern "C" int vnl_prof_read(unsigned long long* out) {
 }
 #endif
 
+// ---- rollout post-processing (include/vnl.h: vnl_rollout_post) ----------------------------------
+// One workgroup per env: the episode / auto-reset decision is taken once, then every op moves its
+// row (coalesced 32-bit words).  HBM-bound: ~5 KB per env.
+#ifndef VNL_POST_THREADS
+#define VNL_POST_THREADS 256
+#endif
+__global__ void __launch_bounds__(VNL_POST_THREADS) vnl_post_kernel(vnl_post_desc d) {
+  const unsigned e = blockIdx.x, tid = threadIdx.x;
+  // every thread evaluates the (cheap) decision itself from the OLD values; thread 0 stores the new ones
+  // only after all threads have read them
+  float st = d.steps ? ((d.prev_done && d.prev_done[e] != 0.f) ? 0.f : d.steps[e]) + (float)d.action_repeat : 0.f;
+  float done = d.done[e];
+  bool over = d.steps && st >= (float)d.episode_length;
+  float trunc = over ? 1.f - done : 0.f;
+  done = over ? 1.f : done;
+  __syncthreads();
+  if (tid == 0) {
+    if (d.steps) d.steps[e] = st;
+    if (d.prev_done) d.prev_done[e] = done;
+    d.done[e] = done;
+    if (d.truncation) d.truncation[e] = trunc;
+    if (d.log_reward) d.log_reward[e] = d.reward[e];
+    if (d.log_discount) d.log_discount[e] = 1.f - done;
+    if (d.log_truncation) d.log_truncation[e] = trunc;
+  }
+  const bool reset = done != 0.f;
+  for (int k = 0; k < d.num_ops; k++) {
+    const vnl_post_op& op = d.ops[k];
+    const bool from_first = op.first && reset;
+    const unsigned* src = (const unsigned*)(from_first ? op.first : op.src) + (size_t)e * op.width;
+    unsigned* dst = op.dst ? (unsigned*)op.dst + (size_t)e * op.width : nullptr;
+    unsigned* log = op.log ? (unsigned*)op.log + (size_t)e * op.width : nullptr;
+    const bool store = dst && (from_first || (const float*)op.dst != op.src);
+    for (int i = (int)tid; i < op.width; i += VNL_POST_THREADS) {
+      unsigned v = src[i];
+      if (store) dst[i] = v;
+      if (log) log[i] = v;
+    }
+  }
+}
+
+extern "C" int vnl_rollout_post(const vnl_post_desc* desc, int32_t num_envs, void* stream) {
+  if (!desc || num_envs <= 0 || !desc->done) return fail(VNL_ERR_ARG, "vnl_rollout_post: null argument");
+  if (desc->num_ops < 0 || desc->num_ops > VNL_POST_MAX_OPS) return fail(VNL_ERR_ARG, "vnl_rollout_post: too many ops");
+  for (int k = 0; k < desc->num_ops; k++)
+    if (!desc->ops[k].src || desc->ops[k].width <= 0) return fail(VNL_ERR_ARG, "vnl_rollout_post: bad op");
+  if ((desc->log_reward && !desc->reward)) return fail(VNL_ERR_ARG, "vnl_rollout_post: log_reward without reward");
+  hipLaunchKernelGGL(vnl_post_kernel, dim3(num_envs), dim3(VNL_POST_THREADS), 0, (hipStream_t)stream, *desc);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
 // the policy-forward entry points (vnl_policy_*) live in vnl_policy.hip

@@ -45,12 +45,99 @@ def actor_step(env, env_state: State, policy, key, extra_fields: Sequence[str] =
                               extras={"policy_extras": policy_extras, "state_extras": state_extras})
 
 
+def _fusable(env):
+    """AutoReset(Episode(RodentTracking)) with action_repeat 1 on the native library: the wrappers and the
+    Transition logging of one step then collapse into ONE launch of vnl_rollout_post."""
+    from ..envs import wrappers as W
+
+    if not isinstance(env, W.AutoResetWrapper) or not isinstance(env.env, W.EpisodeWrapper):
+        return None
+    ep, base = env.env, env.env.env
+    if ep.action_repeat != 1 or base is not base.unwrapped or not hasattr(getattr(base, "_L", None), "vnl_rollout_post"):
+        return None
+    return env, ep, base
+
+
+def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int, extra_fields) -> Tuple[State, Transition]:
+    """Same results as the generic loop below (tests compare the two), 3 launches per step besides the
+    policy: observation row copy, env step kernel, vnl_rollout_post."""
+    import ctypes as C
+
+    from .. import _lib
+
+    ar, ep, base = fz
+    st = env_state
+    T, info, dev = unroll_length, env_state.info, env_state.obs.device
+    B = st.obs.shape[0]
+    new = lambda *shape, like: torch.empty((T, *shape), dtype=like.dtype, device=dev)  # noqa: E731
+    obs_log, nobs_log = new(*st.obs.shape, like=st.obs), new(*st.obs.shape, like=st.obs)
+    rew_log, disc_log = new(B, like=st.reward), new(B, like=st.reward)
+    sx_log = {x: new(*info[x].shape, like=info[x]) for x in extra_fields}
+    prev_done = st.done.clone()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+    width = lambda t: 1 if t.dim() == 1 else t.shape[1]  # noqa: E731
+
+    d = _lib.PostDesc()
+    d.steps, d.prev_done, d.done, d.truncation, d.reward = (ptr(info["steps"]), ptr(prev_done), ptr(st.done),
+                                                            ptr(info["truncation"]), ptr(st.reward))
+    d.episode_length, d.action_repeat = ep.episode_length, 1
+    ops = []  # (dst, src, first, log rows [T, B, w] or None)
+    fps = info["first_pipeline_state"]
+    for name in st.pipeline_state._FIELDS:
+        cur = st.pipeline_state.raw(name)
+        ops.append((cur, cur, fps.raw(name), None))
+    ops.append((st.obs, st.obs, info["first_obs"], nobs_log))
+    logged = set()
+    if ar.reset_info:
+        for k2, v in info["first_info"].items():
+            ops.append((info[k2], info[k2], v, sx_log.get(k2)))
+            logged.add(k2)
+    for x in extra_fields:
+        if x not in logged and x != "truncation":
+            ops.append((None, info[x], None, sx_log[x]))
+    n_static = len(ops)
+    px_log: Optional[dict] = None
+    act_log = None
+    for t in range(T):
+        obs_log[t].copy_(st.obs)
+        actions, pex = policy(info["traj"], obs_log[t], key)
+        base.step(st, actions)
+        if px_log is None:
+            act_log = new(*actions.shape, like=actions)
+            px_log = {k2: new(*v.shape, like=v) for k2, v in pex.items()}
+        step_ops = ops[:n_static] + [(None, actions.contiguous(), None, act_log)] + \
+            [(None, v.contiguous(), None, px_log[k2]) for k2, v in pex.items()]
+        assert len(step_ops) <= _lib.POST_MAX_OPS
+        d.num_ops = len(step_ops)
+        keep = []
+        for i, (dst, src, first, log) in enumerate(step_ops):
+            assert src.dtype in (torch.float32, torch.int32) and src.is_contiguous()
+            o = d.ops[i]
+            o.dst, o.src, o.first, o.width = ptr(dst), ptr(src), ptr(first), width(src)
+            o.log = ptr(log[t]) if log is not None else C.c_void_p(0)
+            keep.append(src)
+        d.log_reward, d.log_discount = ptr(rew_log[t]), ptr(disc_log[t])
+        d.log_truncation = ptr(sx_log["truncation"][t]) if "truncation" in sx_log else C.c_void_p(0)
+        _lib.check(base._L, base._L.vnl_rollout_post(C.byref(d), B, stream))
+        _generate_unroll_fused.hold = keep  # the launch is asynchronous: keep this step's sources alive
+    data = Transition(observation=obs_log, action=act_log, reward=rew_log, discount=disc_log, next_observation=nobs_log,
+                      extras={"policy_extras": px_log, "state_extras": sx_log})
+    return st, data
+
+
 def generate_unroll(env, env_state: State, policy, key, unroll_length: int,
-                    extra_fields: Sequence[str] = ()) -> Tuple[State, Transition]:
+                    extra_fields: Sequence[str] = (), fused: Optional[bool] = None) -> Tuple[State, Transition]:
     """acting.py:60-80: Transitions stacked on a leading time axis [T, B, ...], written row by row into
     buffers allocated once per call (the env mutates its State in place).
     NB (reference behaviour): state_extras['traj'] is nstate.info['traj'], i.e. the reference
-    trajectory features AFTER the step (acting.py:49), not the ones the policy saw."""
+    trajectory features AFTER the step (acting.py:49), not the ones the policy saw.
+    `fused` (default: whenever possible) routes the wrappers + logging through vnl_rollout_post."""
+    fz = _fusable(env) if fused is not False else None
+    if fused is True and fz is None:
+        raise ValueError("fused rollout needs AutoResetWrapper(EpisodeWrapper(RodentTracking)), action_repeat 1")
+    if fz is not None:
+        return _generate_unroll_fused(fz, env_state, policy, key, unroll_length, tuple(extra_fields))
     data: Optional[Transition] = None
     for t in range(unroll_length):
         env_state, tr = actor_step(env, env_state, policy, key, extra_fields=extra_fields)
