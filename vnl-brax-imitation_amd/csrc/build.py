@@ -21,10 +21,28 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
           (["-DVNL_PROFILE"] if profile else []) + [os.path.join(HERE, s) for s in SOURCES]
+    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if verbose or r.returncode:
+        sys.stderr.write(r.stderr)
+    if r.returncode:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    # The env kernels must keep two waves per SIMD (8 workgroups per CU) and no private-memory stack: a
+    # build that slipped to 256 VGPRs + AGPR/scratch spills produced wrong results on the GPU (r01).
+    name, bad = None, []
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif name and ("vnl_step_kernel" in name or "vnl_reset_kernel" in name) and not profile:
+            if "ScratchSize" in line and int(line.split("]:")[1].split()[0]) != 0:
+                bad.append(f"{name}: {line.split('remark:')[1].strip()}")
+            if "Occupancy [waves/SIMD]" in line and int(line.split("]:")[1].split()[0]) < 2:
+                bad.append(f"{name}: {line.split('remark:')[1].strip()}")
+    if bad:
+        os.remove(out)
+        raise RuntimeError("register budget exceeded, refusing to ship this build:\n  " + "\n  ".join(bad))
     return out
 
 

@@ -746,6 +746,12 @@ struct EnvWave {
     const vreal* row = s + L.LD + adr;
     vreal acc = vreal(0.);
     int t = 1;
+    for (; t + 7 <= dep; t += 8) {  // eight independent index->value chains per trip: two LDS round trips
+      int j0 = an[t], j1 = an[t + 1], j2 = an[t + 2], j3 = an[t + 3], j4 = an[t + 4], j5 = an[t + 5], j6 = an[t + 6], j7 = an[t + 7];
+      vreal l0 = row[t], l1 = row[t + 1], l2 = row[t + 2], l3 = row[t + 3], l4 = row[t + 4], l5 = row[t + 5], l6 = row[t + 6], l7 = row[t + 7];
+      acc += (l0 * s[in + j0] + l1 * s[in + j1] + l2 * s[in + j2] + l3 * s[in + j3]) +
+             (l4 * s[in + j4] + l5 * s[in + j5] + l6 * s[in + j6] + l7 * s[in + j7]);
+    }
     for (; t + 3 <= dep; t += 4) {
       int j0 = an[t], j1 = an[t + 1], j2 = an[t + 2], j3 = an[t + 3];
       vreal l0 = row[t], l1 = row[t + 1], l2 = row[t + 2], l3 = row[t + 3];
@@ -772,6 +778,12 @@ struct EnvWave {
       const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
       const vreal* ld = s + L.LD - da;
       int i = a + 1, iend = a + nd;
+      for (; i + 7 <= iend; i += 8) {
+        int e0 = ea[i], e1 = ea[i + 1], e2 = ea[i + 2], e3 = ea[i + 3], e4 = ea[i + 4], e5 = ea[i + 5], e6 = ea[i + 6], e7 = ea[i + 7];
+        vreal x0 = s[in + i], x1 = s[in + i + 1], x2 = s[in + i + 2], x3 = s[in + i + 3];
+        vreal x4 = s[in + i + 4], x5 = s[in + i + 5], x6 = s[in + i + 6], x7 = s[in + i + 7];
+        acc += (ld[e0] * x0 + ld[e1] * x1 + ld[e2] * x2 + ld[e3] * x3) + (ld[e4] * x4 + ld[e5] * x5 + ld[e6] * x6 + ld[e7] * x7);
+      }
       for (; i + 3 <= iend; i += 4) {
         int e0 = ea[i], e1 = ea[i + 1], e2 = ea[i + 2], e3 = ea[i + 3];
         vreal x0 = s[in + i], x1 = s[in + i + 1], x2 = s[in + i + 2], x3 = s[in + i + 3];
