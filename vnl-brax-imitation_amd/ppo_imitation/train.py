@@ -104,12 +104,16 @@ def train(
     kl_weight: float = 1e-4,
     reset_info_on_autoreset: bool = False,
     capture_graph: Optional[bool] = None,
+    restore_from: Optional[str] = None,
 ):
     """PPO training (train.py:62-491).
 
     `num_envs`, `batch_size` are GLOBAL counts as in the reference (train.py:128-129 scales them by
     the device count); each rank owns `num_envs // world` envs -- `environment.num_envs` must equal
     that -- and `batch_size // world` trajectories per minibatch.
+
+    `restore_from`: a file written by `checkpoint.save_params` (full training state if it holds one, else
+    the inference pair only) -- the reference cannot resume.
 
     `capture_graph` (default: on for HIP devices): the minibatch step (gather -> loss -> backward
     [-> Adam when single-GPU]) is captured once into a hipGraph and replayed -- the eager step is
@@ -158,6 +162,19 @@ def train(
         normalizer_params=running_statistics.init_state(env_state.obs.shape[-1], device=device),
         env_steps=0,
     )
+
+    if restore_from is not None:
+        from . import checkpoint
+
+        ck = checkpoint.load_params(restore_from, ppo_network, device=device)
+        with torch.no_grad():
+            flat[:n_pol].copy_(ck["params"][1])
+            if "value" in ck:
+                flat[n_pol:].copy_(ck["value"])
+            for k, v in ck.get("optimizer", {}).items():
+                training_state.optimizer_state[k].copy_(v)
+        training_state.normalizer_params = ck["params"][0]
+        training_state.env_steps = ck.get("env_steps", 0)
 
     def split(p: torch.Tensor) -> ppo_losses.PPONetworkParams:
         return ppo_losses.PPONetworkParams(policy=p[:n_pol], value=p[n_pol:])
@@ -376,4 +393,5 @@ def train(
         dist.barrier()
     params = inference_params()
     train.last_training_state = training_state  # value net / optimiser for checkpoint-resume (beyond the reference)
+    train.last_ppo_network = ppo_network
     return make_policy, params, metrics
