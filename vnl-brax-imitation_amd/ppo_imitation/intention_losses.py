@@ -38,11 +38,16 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
         truncation_mask = 1 - truncation
         values_t_plus_1 = torch.cat([values[1:], bootstrap_value[None]], dim=0)
         deltas = (rewards + discount * (1 - termination) * values_t_plus_1 - values) * truncation_mask
-        acc = torch.zeros_like(bootstrap_value)
-        out = torch.empty_like(values)
-        for t in range(values.shape[0] - 1, -1, -1):
-            acc = deltas[t] + discount * (1 - termination[t]) * truncation_mask[t] * lambda_ * acc
-            out[t] = acc
+        # acc_t = deltas_t + coef_t * acc_{t+1} (intention_losses.py:69-79, a reverse lax.scan) as a scan by
+        # doubling: log2(T) rounds of whole-array ops instead of T tiny sequential steps (launch-bound on a GPU)
+        coef = discount * (1 - termination) * truncation_mask * lambda_
+        out = deltas.clone()
+        T = values.shape[0]
+        k = 1
+        while k < T:
+            out = torch.cat([out[:T - k] + coef[:T - k] * out[k:], out[T - k:]], dim=0)
+            coef = torch.cat([coef[:T - k] * coef[k:], coef[T - k:]], dim=0)
+            k *= 2
         vs = out + values
         vs_t_plus_1 = torch.cat([vs[1:], bootstrap_value[None]], dim=0)
         advantages = (rewards + discount * (1 - termination) * vs_t_plus_1 - values) * truncation_mask
