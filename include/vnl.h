@@ -190,6 +190,25 @@ typedef struct vnl_post_desc {
 } vnl_post_desc;
 int vnl_rollout_post(const vnl_post_desc*, int32_t num_envs, void* stream);
 
+/* ---- PPO loss head: everything of compute_ppo_intention_loss after the network forward passes ----
+ * (reference ppo_imitation/intention_losses.py:26-87 compute_gae, :131-202 loss) in three small launches: GAE,
+ * advantage normalisation, tanh-Normal log-prob and entropy, clipped surrogate, value loss, latent KL,
+ * their sum, AND the gradients of that sum w.r.t. the four network outputs.  Arrays are time-major
+ * [T][B] (index t*B + b) float32 device buffers; logits [T*B][2*act], latents [T*B][latent]. */
+typedef struct vnl_ppo_head_args {
+  int32_t T, B, act, latent;
+  const float *logits, *baseline, *bootstrap, *lat_mean, *lat_logvar;       /* network outputs */
+  const float *raw_action, *behaviour_log_prob, *reward, *truncation, *discount, *eps_entropy;
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon, kl_weight, min_std, var_scale;
+  int32_t normalize_advantage, pad_;
+  float *g_logits, *g_baseline, *g_lat_mean, *g_lat_logvar; /* d total_loss / d (network outputs) */
+  float *vs, *advantages;                                   /* [T*B] GAE outputs (advantages before normalisation) */
+  float *metrics; /* [8]: total_loss, policy_loss, v_loss, entropy_loss, kl_loss_intention, explained_variance, 0, 0 */
+} vnl_ppo_head_args;
+/* workspace: 4 + 4 * 256 floats of device memory (statistics and per-block partial sums) */
+#define VNL_PPO_HEAD_WORKSPACE_FLOATS (4 + 4 * 256)
+int vnl_ppo_head(const vnl_ppo_head_args*, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

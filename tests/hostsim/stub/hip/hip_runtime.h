@@ -45,6 +45,10 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_PREFIX_PER_LANE 512
 #define VNL_ROWSETS_1 64
 #define VNL_POST_THREADS 1
+#define VNL_HEAD_THREADS 1
+#define VNL_HEAD_GROUP 1
+#define VNL_GROUP_SUM(v) (void)(v)
+#define __shared__
 #define VNL_ROWSETS_2 128
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)

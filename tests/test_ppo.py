@@ -167,3 +167,60 @@ def test_train_runs_and_returns_reference_triple():
     assert float(norm.count) == 160 and flat.dim() == 1  # 4 training steps x 8 envs x 5 steps
     act, extras = make_policy(params, deterministic=True)(torch.zeros(2, 795), torch.zeros(2, 232), None)
     assert act.shape == (2, 30) and extras == {}
+
+
+def _loss_both_ways(n, pf, vf, device, lib, B=16, T=7, seed=5):
+    rng = np.random.default_rng(seed)
+    d = _fake_batch(B, T, rng)
+    d["log_prob"] = d["log_prob"] + 20 - 25  # keep rho = exp(target - behaviour) near the clipping range ...
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device=device)  # noqa: E731
+    data = acting.Transition(f(d["observation"]), torch.zeros(B, T, 30, device=device), f(d["reward"]), f(d["discount"]),
+                             f(d["next_observation"]),
+                             {"policy_extras": {"raw_action": f(d["raw_action"]), "log_prob": f(d["log_prob"])},
+                              "state_extras": {"truncation": f(d["truncation"]), "traj": f(d["traj"])}})
+    noise = {"latent": f(rng.standard_normal((T, B, 64))), "entropy": f(rng.standard_normal((T, B, 30)))}
+    st = running_statistics.init_state(232, device=device)
+    kw = dict(entropy_cost=1e-2, discounting=0.97, reward_scaling=2.0, gae_lambda=0.9, clipping_epsilon=0.3,
+              normalize_advantage=True, kw_dummy=None)
+    kw.pop("kw_dummy")
+    # ... by making the behaviour log-prob the current one plus noise (as in a real PPO epoch)
+    with torch.no_grad():
+        lg, _, _ = n.policy_network.apply(st, pf.to(device), data.extras["state_extras"]["traj"].transpose(0, 1),
+                                          data.observation.transpose(0, 1), noise["latent"])
+        cur = n.parametric_action_distribution.log_prob(lg, data.extras["policy_extras"]["raw_action"].transpose(0, 1))
+        data.extras["policy_extras"]["log_prob"] = (cur + 0.4 * f(rng.standard_normal((T, B)))).transpose(0, 1).contiguous()
+    out = []
+    for head in ("torch", lib):
+        params = intention_losses.PPONetworkParams(policy=pf.clone().to(device).requires_grad_(True),
+                                                   value=vf.clone().to(device).requires_grad_(True))
+        loss, m = intention_losses.compute_ppo_intention_loss(params, st, data, None, ppo_network=n, noise=noise,
+                                                              kl_weight=3e-3, head=head, **kw)
+        loss.backward()
+        out.append((loss.detach(), m, params.policy.grad.clone(), params.value.grad.clone()))
+    return out
+
+
+def _check_head(out):
+    (l0, m0, gp0, gv0), (l1, m1, gp1, gv1) = out
+    for k in m0:
+        a, b = float(m0[k]), float(m1[k])
+        assert abs(a - b) < 2e-5 * max(1.0, abs(a)), (k, a, b)
+    assert abs(float(l0) - float(l1)) < 2e-5 * max(1.0, abs(float(l0)))
+    for g0, g1 in ((gp0, gp1), (gv0, gv1)):
+        scale = float(g0.abs().max())
+        assert scale > 0 and float((g0 - g1).abs().max()) < 2e-4 * scale, (scale, float((g0 - g1).abs().max()))
+    assert 1e-3 < float((m0["policy_loss"]).abs()) < 10  # a non-degenerate surrogate (rho spread around the clip range)
+
+
+def test_fused_loss_head_matches_autograd_hostsim(nets):
+    """vnl_ppo_head (loss head + gradients in one launch) against the op-by-op torch loss and ITS autograd."""
+    n, pf, vf = nets
+    _check_head(_loss_both_ways(n, pf, vf, torch.device("cpu"), H.hostsim_library("float")))
+
+
+@pytest.mark.gpu
+def test_fused_loss_head_matches_autograd_gpu(nets):
+    from vnl_brax_imitation_amd import _lib
+
+    n, pf, vf = nets
+    _check_head(_loss_both_ways(n, pf, vf, torch.device("cuda:0"), _lib.load_library(), B=128, T=20))

@@ -87,10 +87,23 @@ class PostDesc(C.Structure):  # include/vnl.h: vnl_post_desc
                 ("pad_", C.c_int32), ("ops", PostOp * POST_MAX_OPS)]
 
 
+class PPOHeadArgs(C.Structure):  # include/vnl.h: vnl_ppo_head_args
+    _fields_ = [(n, C.c_int32) for n in ("T", "B", "act", "latent")] + \
+               [(n, C.c_void_p) for n in ("logits", "baseline", "bootstrap", "lat_mean", "lat_logvar", "raw_action",
+                                          "behaviour_log_prob", "reward", "truncation", "discount", "eps_entropy")] + \
+               [(n, C.c_float) for n in ("entropy_cost", "discounting", "reward_scaling", "gae_lambda",
+                                         "clipping_epsilon", "kl_weight", "min_std", "var_scale")] + \
+               [("normalize_advantage", C.c_int32), ("pad_", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("g_logits", "g_baseline", "g_lat_mean", "g_lat_logvar", "vs", "advantages",
+                                          "metrics")]
+
+
+PPO_HEAD_WORKSPACE_FLOATS = 4 + 4 * 256
+
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
     "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
-    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post",
+    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head",
 )
 
 
@@ -114,6 +127,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_debug.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.vnl_rollout_post.argtypes = [C.POINTER(PostDesc), C.c_int32, vp]
+    lib.vnl_ppo_head.argtypes = [C.POINTER(PPOHeadArgs), vp, vp]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
         lib.vnl_policy_destroy.argtypes = [vp]

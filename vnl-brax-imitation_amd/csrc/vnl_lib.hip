@@ -650,4 +650,164 @@ extern "C" int vnl_rollout_post(const vnl_post_desc* desc, int32_t num_envs, voi
   return VNL_OK;
 }
 
+// ---- PPO loss head (include/vnl.h: vnl_ppo_head) -------------------------------------------------
+// Three launches on the caller's stream: (1) GAE, one column per thread, + advantage / reward statistics;
+// (2) the per-sample head, 32 lanes per sample (lane = action component: coalesced rows, shuffle sums),
+// per-block partial sums; (3) the partials summed in a fixed order -> metrics (deterministic).
+#ifndef VNL_HEAD_THREADS
+#define VNL_HEAD_THREADS 256
+#define VNL_HEAD_GROUP 32
+#define VNL_GROUP_SUM(v) \
+  (v += __shfl_xor(v, 16, 32), v += __shfl_xor(v, 8, 32), v += __shfl_xor(v, 4, 32), v += __shfl_xor(v, 2, 32), v += __shfl_xor(v, 1, 32))
+#endif
+#define VNL_HEAD_MAXBLK 256
+__device__ __forceinline__ float vnl_block_sum(float v, float* red) {
+  const unsigned tid = threadIdx.x;
+  __syncthreads();
+  red[tid] = v;
+  __syncthreads();
+  for (unsigned w = VNL_HEAD_THREADS / 2; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  return red[0];
+}
+__device__ __forceinline__ float vnl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch F.softplus
+
+// stats: [0] adv mean, [1] adv std (biased), [2] reward variance (biased), then VNL_HEAD_MAXBLK x 4 partial sums
+__global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_gae_kernel(vnl_ppo_head_args a, float* stats) {
+#if VNL_HEAD_THREADS > 1
+  __shared__ float red[VNL_HEAD_THREADS];
+#else
+  float red[1];
+#endif
+  const int tid = (int)threadIdx.x, T = a.T, B = a.B, N = T * B;
+  // compute_gae: reverse scan, intention_losses.py:63-87
+  float sa = 0.f, sr = 0.f;
+  for (int b = tid; b < B; b += VNL_HEAD_THREADS) {
+    float acc = 0.f, v_next = a.bootstrap[b], vs_next = a.bootstrap[b];
+    for (int t = T - 1; t >= 0; t--) {
+      const int n = t * B + b;
+      const float trunc = a.truncation[n], mask = 1.f - trunc;
+      const float term = (1.f - a.discount[n]) * (1.f - trunc);
+      const float r = a.reward[n] * a.reward_scaling, v = a.baseline[n];
+      const float delta = (r + a.discounting * (1.f - term) * v_next - v) * mask;
+      acc = delta + a.discounting * (1.f - term) * mask * a.gae_lambda * acc;
+      const float vs = acc + v;
+      const float adv = (r + a.discounting * (1.f - term) * vs_next - v) * mask;
+      a.vs[n] = vs, a.advantages[n] = adv;
+      sa += adv, sr += r;
+      v_next = v, vs_next = vs;
+    }
+  }
+  const float adv_mean = vnl_block_sum(sa, red) / (float)N, r_mean = vnl_block_sum(sr, red) / (float)N;
+  float qa = 0.f, qr = 0.f;
+  __syncthreads();
+  for (int n = tid; n < N; n += VNL_HEAD_THREADS) {
+    const float da = a.advantages[n] - adv_mean, dr = a.reward[n] * a.reward_scaling - r_mean;
+    qa += da * da, qr += dr * dr;
+  }
+  const float va = vnl_block_sum(qa, red) / (float)N, vr = vnl_block_sum(qr, red) / (float)N;
+  if (tid == 0) stats[0] = adv_mean, stats[1] = sqrtf(va), stats[2] = vr;
+}
+
+__global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_head_kernel(vnl_ppo_head_args a, float* stats) {
+#if VNL_HEAD_THREADS > 1
+  __shared__ float red[VNL_HEAD_THREADS];
+#else
+  float red[1];
+#endif
+  const int tid = (int)threadIdx.x, A = a.act, N = a.T * a.B;
+  const int lane = tid % VNL_HEAD_GROUP, group = (int)(blockIdx.x * (VNL_HEAD_THREADS / VNL_HEAD_GROUP)) + tid / VNL_HEAD_GROUP;
+  const int ngroups = (int)gridDim.x * (VNL_HEAD_THREADS / VNL_HEAD_GROUP);
+  const float adv_mean = stats[0], adv_std = stats[1];
+  const float inv_n = 1.f / (float)N, half_log_2pi = 0.91893853320467274178f, ln2 = 0.69314718055994530942f;
+  const float lo = 1.f - a.clipping_epsilon, hi = 1.f + a.clipping_epsilon;
+  float s_pl = 0.f, s_vl = 0.f, s_ent = 0.f;  // counted once per sample (lane 0 of the group)
+  for (int n = group; n < N; n += ngroups) {
+    const float* lg = a.logits + (size_t)n * 2 * A;
+    const float* ra = a.raw_action + (size_t)n * A;
+    const float* ee = a.eps_entropy + (size_t)n * A;
+    // tanh-Normal log-prob of the stored raw action and entropy estimate at loc + scale * eps, summed over actions
+    float tlp = 0.f, ent = 0.f;
+    for (int k = lane; k < A; k += VNL_HEAD_GROUP) {
+      const float loc = lg[k], scale = (vnl_softplus(lg[A + k]) + a.min_std) * a.var_scale;
+      const float x = ra[k], z = (x - loc) / scale, lsc = logf(scale);
+      tlp += (-0.5f * z * z - half_log_2pi - lsc) - 2.f * (ln2 - x - vnl_softplus(-2.f * x));
+      const float xe = loc + scale * ee[k];
+      ent += (0.5f + half_log_2pi + lsc) + 2.f * (ln2 - xe - vnl_softplus(-2.f * xe));
+    }
+    VNL_GROUP_SUM(tlp);
+    VNL_GROUP_SUM(ent);
+    float adv = a.advantages[n];
+    if (a.normalize_advantage) adv = (adv - adv_mean) / (adv_std + 1e-8f);
+    const float rho = expf(tlp - a.behaviour_log_prob[n]);
+    const float rc = fminf(fmaxf(rho, lo), hi);
+    const float s1 = rho * adv, s2 = rc * adv;
+    // d min(s1, s2) / d rho: adv where the unclipped branch is active (ties: both branches agree), else 0
+    const float dmin = (s1 < s2 || (s1 == s2 && rho >= lo && rho <= hi)) ? adv : ((s1 == s2) ? 0.5f * adv : 0.f);
+    const float g_tlp = -inv_n * dmin * rho;      // d policy_loss / d target_log_prob
+    const float g_ent = -a.entropy_cost * inv_n;  // d entropy_loss / d entropy_n
+    const float verr = a.vs[n] - a.baseline[n];
+    if (lane == 0) {
+      s_pl += -fminf(s1, s2), s_vl += verr * verr, s_ent += ent;
+      a.g_baseline[n] = -0.5f * verr * inv_n;  // v_loss = 0.25 mean(verr^2)
+    }
+    float* gl = a.g_logits + (size_t)n * 2 * A;
+    for (int k = lane; k < A; k += VNL_HEAD_GROUP) {
+      const float sraw = lg[A + k], scale = (vnl_softplus(sraw) + a.min_std) * a.var_scale;
+      const float loc = lg[k], z = (ra[k] - loc) / scale, xe = loc + scale * ee[k], th = tanhf(xe);
+      const float dscale_ds = a.var_scale / (1.f + expf(-sraw));  // softplus' = sigmoid
+      gl[k] = g_tlp * (z / scale) + g_ent * (-2.f * th);
+      gl[A + k] = (g_tlp * ((z * z - 1.f) / scale) + g_ent * (1.f / scale - 2.f * th * ee[k])) * dscale_ds;
+    }
+  }
+  // latent KL (kl_divergence: a mean over samples x latent), intention_losses.py:21-23
+  float s_kl = 0.f;
+  const int NL = N * a.latent;
+  const float kscale = a.kl_weight / (float)NL;
+  for (int i = (int)(blockIdx.x * VNL_HEAD_THREADS) + tid; i < NL; i += (int)gridDim.x * VNL_HEAD_THREADS) {
+    const float mu = a.lat_mean[i], lv = a.lat_logvar[i], ev = expf(lv);
+    s_kl += 1.f + lv - mu * mu - ev;
+    a.g_lat_mean[i] = kscale * mu;
+    a.g_lat_logvar[i] = -0.5f * kscale * (1.f - ev);
+  }
+  const float p0 = vnl_block_sum(s_pl, red), p1 = vnl_block_sum(s_vl, red), p2 = vnl_block_sum(s_ent, red),
+              p3 = vnl_block_sum(s_kl, red);
+  if (tid == 0) {
+    float* part = stats + 4 + 4 * blockIdx.x;
+    part[0] = p0, part[1] = p1, part[2] = p2, part[3] = p3;
+  }
+}
+
+__global__ void vnl_ppo_finish_kernel(vnl_ppo_head_args a, const float* stats, int nblk) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nblk; b++)
+    for (int k = 0; k < 4; k++) s[k] += stats[4 + 4 * b + k];
+  const int N = a.T * a.B;
+  const float inv_n = 1.f / (float)N, kscale = a.kl_weight / (float)(N * a.latent);
+  const float pl = s[0] * inv_n, vl = 0.25f * s[1] * inv_n, el = -a.entropy_cost * s[2] * inv_n, kl = -0.5f * kscale * s[3];
+  a.metrics[0] = pl + vl + el + kl, a.metrics[1] = pl, a.metrics[2] = vl, a.metrics[3] = el, a.metrics[4] = kl;
+  a.metrics[5] = 1.f - vl / stats[2], a.metrics[6] = stats[0], a.metrics[7] = stats[1];
+}
+
+extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* stream) {
+  if (!a || !workspace || a->T <= 0 || a->B <= 0 || a->act <= 0 || a->latent <= 0)
+    return fail(VNL_ERR_ARG, "vnl_ppo_head: bad sizes");
+  const void* need[] = {a->logits, a->baseline, a->bootstrap, a->lat_mean, a->lat_logvar, a->raw_action,
+                        a->behaviour_log_prob, a->reward, a->truncation, a->discount, a->eps_entropy, a->g_logits,
+                        a->g_baseline, a->g_lat_mean, a->g_lat_logvar, a->vs, a->advantages, a->metrics};
+  for (const void* p : need)
+    if (!p) return fail(VNL_ERR_ARG, "vnl_ppo_head: null buffer");
+  const int groups_per_block = VNL_HEAD_THREADS / VNL_HEAD_GROUP, N = a->T * a->B;
+  int nblk = (N + groups_per_block - 1) / groups_per_block;
+  if (nblk > VNL_HEAD_MAXBLK) nblk = VNL_HEAD_MAXBLK;
+  hipLaunchKernelGGL(vnl_ppo_gae_kernel, dim3(1), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
+  hipLaunchKernelGGL(vnl_ppo_head_kernel, dim3(nblk), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
+  hipLaunchKernelGGL(vnl_ppo_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *a, (const float*)workspace, nblk);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
 // the policy-forward entry points (vnl_policy_*) live in vnl_policy.hip

@@ -54,6 +54,58 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
     return vs, advantages
 
 
+class _PPOHead(torch.autograd.Function):
+    """vnl_ppo_head (csrc/vnl_lib.hip): loss head + its gradients in one launch.  forward() returns the total
+    loss and stashes d loss / d (logits, baseline, latent mean, latent logvar) for backward()."""
+
+    @staticmethod
+    def forward(ctx, logits, baseline, lat_mean, lat_logvar, bootstrap, raw_action, behaviour_lp, reward, truncation,
+                discount, eps_entropy, cfg, lib):
+        import ctypes as C
+
+        from .. import _lib
+
+        T, B = baseline.shape
+        c = lambda t: t.detach().contiguous()  # noqa: E731
+        ins = [c(t) for t in (logits, baseline, bootstrap, lat_mean, lat_logvar, raw_action, behaviour_lp, reward,
+                              truncation, discount, eps_entropy)]
+        g = [torch.empty_like(ins[0]), torch.empty_like(ins[1]), torch.empty_like(ins[3]), torch.empty_like(ins[4])]
+        vs, adv = torch.empty_like(ins[1]), torch.empty_like(ins[1])
+        metrics = torch.empty(8, dtype=torch.float32, device=baseline.device)
+        work = torch.empty(_lib.PPO_HEAD_WORKSPACE_FLOATS, dtype=torch.float32, device=baseline.device)
+        a = _lib.PPOHeadArgs()
+        a.T, a.B, a.act, a.latent = T, B, raw_action.shape[-1], lat_mean.shape[-1]
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        (a.logits, a.baseline, a.bootstrap, a.lat_mean, a.lat_logvar, a.raw_action, a.behaviour_log_prob, a.reward,
+         a.truncation, a.discount, a.eps_entropy) = [ptr(t) for t in ins]
+        for k, v in cfg.items():
+            setattr(a, k, v)
+        a.g_logits, a.g_baseline, a.g_lat_mean, a.g_lat_logvar = [ptr(t) for t in g]
+        a.vs, a.advantages, a.metrics = ptr(vs), ptr(adv), ptr(metrics)
+        dev = baseline.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(lib, lib.vnl_ppo_head(C.byref(a), ptr(work), stream))
+        ctx.save_for_backward(*g)
+        ctx.hold = ins + [work]  # buffers of asynchronous launches
+        ctx.mark_non_differentiable(vs, metrics)
+        return metrics[0].clone(), vs, metrics
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_vs, _g_metrics):
+        gl, gb, gm, gv = ctx.saved_tensors
+        return (gl * g_loss, gb * g_loss, gm * g_loss, gv * g_loss) + (None,) * 9
+
+
+def _head_library(dev):
+    """The native library when it can run the loss head on `dev` (HIP device, float32); None otherwise."""
+    if dev.type != "cuda":
+        return None
+    from .. import _lib
+
+    lib = _lib.load_library()
+    return lib if hasattr(lib, "vnl_ppo_head") else None
+
+
 def compute_ppo_intention_loss(
     params: PPONetworkParams,
     normalizer_params: Any,
@@ -68,9 +120,12 @@ def compute_ppo_intention_loss(
     normalize_advantage: bool = True,
     kl_weight: float = 1e-4,
     noise: Optional[Dict[str, torch.Tensor]] = None,
+    head: Any = "auto",
 ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """intention_losses.py:91-202.  `data` has leading dims [B, T]; `noise` optionally supplies the
-    two Gaussian draws ('latent' [T,B,latent], 'entropy' [T,B,act]) for reproducible tests."""
+    two Gaussian draws ('latent' [T,B,latent], 'entropy' [T,B,act]) for reproducible tests.
+    `head`: "auto" = the fused HIP loss head (vnl_ppo_head) on a HIP device, "torch" = op by op (the
+    reference's formulation, also what autograd-checks the kernel in the tests), or a loaded library."""
     dist = ppo_network.parametric_action_distribution
     policy_apply = ppo_network.policy_network.apply
     value_apply = ppo_network.value_network.apply
@@ -90,11 +145,27 @@ def compute_ppo_intention_loss(
 
     policy_logits, intention_mean, intention_logvar = policy_apply(
         normalizer_params, params.policy, data.extras["state_extras"]["traj"], obs, draw("latent", (T, B, latent)))
-    baseline = value_apply(normalizer_params, params.value, obs)
-    bootstrap_value = value_apply(normalizer_params, params.value, data.next_observation[-1])
+    # one value-network pass over the T observations and the bootstrap observation (:135-137 calls it twice)
+    values_all = value_apply(normalizer_params, params.value, torch.cat([obs, data.next_observation[-1:]], dim=0))
+    baseline, bootstrap_value = values_all[:-1], values_all[-1].detach()
+
+    truncation = data.extras["state_extras"]["truncation"]
+    lib = _head_library(dev) if head == "auto" else (None if head == "torch" else head)
+    if lib is not None:
+        cfg = dict(entropy_cost=entropy_cost, discounting=discounting, reward_scaling=reward_scaling,
+                   gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon, kl_weight=kl_weight, min_std=dist._min_std,
+                   var_scale=dist._var_scale, normalize_advantage=int(normalize_advantage))
+        total_loss, vs, mt = _PPOHead.apply(
+            policy_logits, baseline, intention_mean, intention_logvar, bootstrap_value,
+            data.extras["policy_extras"]["raw_action"], data.extras["policy_extras"]["log_prob"], data.reward, truncation,
+            data.discount, draw("entropy", (T, B, dist.event_size)), cfg, lib)
+        with torch.no_grad():
+            rewards = data.reward * reward_scaling
+            prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if T * 2 <= 256 else torch.zeros((), device=dev)
+        return total_loss, {"total_loss": mt[0], "policy_loss": mt[1], "v_loss": mt[2], "entropy_loss": mt[3],
+                            "kl_loss_intention": mt[4], "prediction_corr": prediction_corr, "explained_variance": mt[5]}
 
     rewards = data.reward * reward_scaling
-    truncation = data.extras["state_extras"]["truncation"]
     termination = (1 - data.discount) * (1 - truncation)
 
     target_action_log_probs = dist.log_prob(policy_logits, data.extras["policy_extras"]["raw_action"])
