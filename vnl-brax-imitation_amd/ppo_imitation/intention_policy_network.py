@@ -37,12 +37,33 @@ class ParamLayout:
         self.entries[name] = (self.size, tuple(shape))
         self.size += n
 
-    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+    def view(self, flat, name: str) -> torch.Tensor:
+        if isinstance(flat, LeafParams):
+            return flat.leaves[name]
         off, shape = self.entries[name]
         return flat[off:off + int(math.prod(shape))].view(shape)
 
     def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {k: self.view(flat, k) for k in self.entries}
+
+
+class LeafParams:
+    """A flat parameter buffer presented to autograd as one LEAF per tensor.
+
+    Differentiating through `flat[off:off+n].view(shape)` makes every tensor's backward allocate and add a
+    zero-filled copy of the WHOLE buffer (34 tensors x 6.5 MB x fill/copy/add per minibatch step).  Here each
+    tensor is a leaf that aliases its slice of `flat`, and its `.grad` aliases the same slice of one flat
+    gradient buffer, so autograd accumulates in place and the optimiser / all-reduce still see flat buffers."""
+
+    def __init__(self, layout: "ParamLayout", flat: torch.Tensor, flat_grad: torch.Tensor):
+        assert not flat.requires_grad and flat.shape == flat_grad.shape == (layout.size,)
+        self.layout, self.flat, self.flat_grad = layout, flat, flat_grad
+        self.leaves: Dict[str, torch.Tensor] = {}
+        for name, (off, shape) in layout.entries.items():
+            n = int(math.prod(shape))
+            leaf = flat[off:off + n].view(shape).detach().requires_grad_(True)
+            leaf.grad = flat_grad[off:off + n].view(shape)
+            self.leaves[name] = leaf
 
 
 def lecun_uniform_(t: torch.Tensor, fan_in: int, gen: torch.Generator) -> None:

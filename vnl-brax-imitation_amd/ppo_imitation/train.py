@@ -154,7 +154,7 @@ def train(
     flat = torch.cat([ppo_network.policy_network.init(g_net), ppo_network.value_network.init(g_net)]).to(device)
     if dist is not None:
         dist.broadcast(flat, src=0)  # C3
-    flat.requires_grad_(True)
+    flat_grad = torch.zeros_like(flat)  # d loss / d flat; the per-tensor .grad of the leaves alias it
     optimizer = FlatAdam(learning_rate)
     training_state = TrainingState(
         optimizer_state=optimizer.init(flat.detach()),
@@ -176,8 +176,11 @@ def train(
         training_state.normalizer_params = ck["params"][0]
         training_state.env_steps = ck.get("env_steps", 0)
 
-    def split(p: torch.Tensor) -> ppo_losses.PPONetworkParams:
-        return ppo_losses.PPONetworkParams(policy=p[:n_pol], value=p[n_pol:])
+    from .intention_policy_network import LeafParams
+
+    leaf_params = ppo_losses.PPONetworkParams(
+        policy=LeafParams(ppo_network.policy_network.layout, flat[:n_pol], flat_grad[:n_pol]),
+        value=LeafParams(ppo_network.value_network.layout, flat[n_pol:], flat_grad[n_pol:]))
 
     loss_fn = functools.partial(
         ppo_losses.compute_ppo_intention_loss, ppo_network=ppo_network, entropy_cost=entropy_cost,
@@ -186,14 +189,13 @@ def train(
 
     def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
         """train.py:255-268 + brax gradient_update_fn: grad, all-reduce(mean), adam."""
-        p = training_state.params
-        p.grad = None
-        loss, metrics = loss_fn(split(p), normalizer_params, data, g_dev)
+        flat_grad.zero_()
+        loss, metrics = loss_fn(leaf_params, normalizer_params, data, g_dev)
         loss.backward()
         if dist is not None:
-            dist.all_reduce(p.grad)  # C1: one flat buffer
-            p.grad.div_(world)
-        optimizer.update(p.grad, training_state.optimizer_state, p.data)
+            dist.all_reduce(flat_grad)  # C1: one flat buffer
+            flat_grad.div_(world)
+        optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
         return metrics
 
     if capture_graph is None:
@@ -222,28 +224,27 @@ def train(
                 full.reward.index_select(0, idx), full.discount.index_select(0, idx),
                 full.next_observation[:, -1:].index_select(0, idx),  # only the bootstrap row is read
                 {k: {kk: vv.index_select(0, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
-            loss, metrics = loss_fn(split(p), g["norm"], mbd, None, noise=g["noise"])
+            flat_grad.zero_()
+            loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"])
             loss.backward()
             if dist is None:
-                optimizer.update(p.grad, training_state.optimizer_state, p.data)
+                optimizer.update(flat_grad, training_state.optimizer_state, p)
             return metrics
 
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(3):  # warm-up off the capture stream (library handles, autograd buffers)
-                p.grad = None
                 m = body()
         torch.cuda.current_stream(device).wait_stream(side)
         g["keys"] = sorted(m.keys())
         g["acc"] = torch.zeros(len(g["keys"]), device=device)
-        p.grad = None
         g["graph"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["graph"]):
             m = body()
             g["acc"] += torch.stack([m[k].to(torch.float32).reshape(()) for k in g["keys"]])
         with torch.no_grad():  # the warm-up iterations must not count as training
-            p.data.copy_(saved[0])
+            p.copy_(saved[0])
             for k, v in saved[1].items():
                 training_state.optimizer_state[k].copy_(v)
 
@@ -259,10 +260,9 @@ def train(
                 torch.randn(g["noise"][name].shape, generator=g_dev, device=device, out=g["noise"][name])
             g["graph"].replay()
             if dist is not None:
-                p = training_state.params
-                dist.all_reduce(p.grad)  # C1
-                p.grad.div_(world)
-                optimizer.update(p.grad, training_state.optimizer_state, p.data)
+                dist.all_reduce(flat_grad)  # C1
+                flat_grad.div_(world)
+                optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
         acc = g["acc"] / num_minibatches
         return {k: acc[i] for i, k in enumerate(g["keys"])}
 
