@@ -52,18 +52,32 @@ class LeafParams:
 
     Differentiating through `flat[off:off+n].view(shape)` makes every tensor's backward allocate and add a
     zero-filled copy of the WHOLE buffer (34 tensors x 6.5 MB x fill/copy/add per minibatch step).  Here each
-    tensor is a leaf that aliases its slice of `flat`, and its `.grad` aliases the same slice of one flat
-    gradient buffer, so autograd accumulates in place and the optimiser / all-reduce still see flat buffers."""
+    tensor is a leaf that aliases its slice of `flat`; after backward() the per-tensor gradients are moved into
+    one flat gradient buffer by a single multi-tensor copy, so the optimiser / all-reduce see flat buffers."""
 
     def __init__(self, layout: "ParamLayout", flat: torch.Tensor, flat_grad: torch.Tensor):
         assert not flat.requires_grad and flat.shape == flat_grad.shape == (layout.size,)
         self.layout, self.flat, self.flat_grad = layout, flat, flat_grad
         self.leaves: Dict[str, torch.Tensor] = {}
+        self.grad_views = []
         for name, (off, shape) in layout.entries.items():
             n = int(math.prod(shape))
             leaf = flat[off:off + n].view(shape).detach().requires_grad_(True)
-            leaf.grad = flat_grad[off:off + n].view(shape)
             self.leaves[name] = leaf
+            self.grad_views.append(flat_grad[off:off + n].view(shape))
+
+    def zero_grad(self) -> None:
+        """Before backward(): with .grad unset autograd hands each leaf its gradient tensor as is (no add)."""
+        for leaf in self.leaves.values():
+            leaf.grad = None
+
+    def gather_grads(self) -> None:
+        """After backward(): all per-tensor gradients into the flat gradient buffer, one multi-tensor copy."""
+        leaves = list(self.leaves.values())
+        if any(leaf.grad is None for leaf in leaves):
+            self.flat_grad.zero_()
+        pairs = [(v, leaf.grad) for v, leaf in zip(self.grad_views, leaves) if leaf.grad is not None]
+        torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])
 
 
 def lecun_uniform_(t: torch.Tensor, fan_in: int, gen: torch.Generator) -> None:

@@ -189,9 +189,10 @@ def train(
 
     def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
         """train.py:255-268 + brax gradient_update_fn: grad, all-reduce(mean), adam."""
-        flat_grad.zero_()
+        leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
         loss, metrics = loss_fn(leaf_params, normalizer_params, data, g_dev)
         loss.backward()
+        leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
         if dist is not None:
             dist.all_reduce(flat_grad)  # C1: one flat buffer
             flat_grad.div_(world)
@@ -224,9 +225,10 @@ def train(
                 full.reward.index_select(0, idx), full.discount.index_select(0, idx),
                 full.next_observation[:, -1:].index_select(0, idx),  # only the bootstrap row is read
                 {k: {kk: vv.index_select(0, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
-            flat_grad.zero_()
+            leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
             loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"])
             loss.backward()
+            leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
             if dist is None:
                 optimizer.update(flat_grad, training_state.optimizer_state, p)
             return metrics
