@@ -652,10 +652,20 @@ struct EnvWave {
             const int k = __builtin_ctz(match[q]);
             match[q] &= match[q] - 1u;
             const vreal* line = s + sc + k * LW;
+            // first column chunk fetched together with the pivot entry and 1/D: one LDS round trip, not two
+            // (entries past the row's depth are don't-cares: never published, never stored)
+            R4 x0[CH / 4];
+#pragma unroll
+            for (int c = 0; c < CH; c += 4) x0[c / 4] = ld4a(line + c);
             vreal traw = line[dep[q]];
             vreal t = traw * line[MAXD];
 #pragma unroll
-            for (int c0 = 0; c0 < MAXD; c0 += CH) {
+            for (int c = 0; c < CH; c += 4) {
+              R4 x = x0[c / 4];
+              rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+            }
+#pragma unroll
+            for (int c0 = CH; c0 < MAXD; c0 += CH) {
               if (c0 < dep[q]) {
 #pragma unroll
                 for (int c = c0; c < c0 + CH; c += 4) {
