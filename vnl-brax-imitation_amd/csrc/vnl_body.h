@@ -433,12 +433,31 @@ struct EnvWave {
   // Expects cinert in pool[0..10 nbody) (turned into crb in place).
   VNL_HD void mass_matrix(vreal diag_scale) const {
     tree_accumulate(L.P, 10);
-    VNL_FOR(i, m.nv) {
-      S6 f = inert_mul(L.P + 10 * m.dof_body[i], ld6(L.cdof + 6 * i));
-      int adr = madr(i), dep = eadr(i) - adr;
-      s[L.LD + adr] = dot(f, ld6(L.cdof + 6 * i)) + m.dof_armature[i] + diag_scale * m.dof_damping[i];
-#pragma unroll 2
-      for (int t = 1; t <= dep; t++) s[L.LD + adr + t] = dot(f, ld6(L.cdof + 6 * anc_of(adr + t)));
+    // f_i = crb[body(i)] * cdof_i for every dof, parked in the six CG vectors Ma .. qfrc_c (contiguous,
+    // dead whenever M is built); then one lane per run of consecutive matrix ENTRIES (not per row: rows
+    // have 1 .. max_depth+1 entries): M(i, j) = f_i . cdof_j.
+    const int F = L.Ma;
+    VNL_FOR(i, m.nv) st6(F + 6 * i, inert_mul(L.P + 10 * m.dof_body[i], ld6(L.cdof + 6 * i)));
+    VNL_SYNC();
+    const int per = (m.nM + VNL_LANES - 1) / VNL_LANES;
+    VNL_FOR(l, VNL_LANES) {
+      int e = l * per;
+      const int e1 = e + per < m.nM ? e + per : m.nM;
+      if (e < e1) {
+        int i = m.M_row[e], end = eadr(i);
+        S6 f = ld6(F + 6 * i);
+        for (; e < e1; e++) {
+          if (e > end) {
+            i++;
+            end = eadr(i);
+            f = ld6(F + 6 * i);
+          }
+          const int j = anc_of(e);
+          vreal v = dot(f, ld6(L.cdof + 6 * j));
+          if (j == i) v += m.dof_armature[i] + diag_scale * m.dof_damping[i];
+          s[L.LD + e] = v;
+        }
+      }
     }
     VNL_SYNC();
   }
