@@ -15,9 +15,14 @@ from vnl_brax_imitation_amd import _lib  # noqa: E402
 from vnl_brax_imitation_amd.csrc import build as hb  # noqa: E402
 from vnl_brax_imitation_amd.envs.rodent import RodentTracking  # noqa: E402
 
-NAMES = ["kinematics", "crb+M", "factor(M)", "bias(rne)", "smooth+solveM", "collision+rows", "solver init",
-         "ls: twists+Jv+Mv", "ls: row passes", "update: J'f+cost", "solveM(grad)", "euler pre", "factor(M+hB)",
-         "euler solve+integrate", "env glue", "-"]
+NAMES = ["kinematics", "body inertias (x2)", "bias: velocity prefix", "bias: acceleration prefix", "bias: cfrc + subtree sums + project",
+         "M: crb subtree sums (x2)", "M: f_i + entries (x2)", "factor: load rows (x2)", "factor: steps (x2)", "factor: store (x2)",
+         "M*warm (1st only) [after factor]", "inversion (x2)", "smooth forces", "constraint rows (collision + limits)",
+         "solve: warm-start choice (2 J*v + costs)", "solve: J'f + first M^-1 grad", "iter: convergence test + |search|",
+         "iter: J*search", "iter: qg sums", "iter: line search", "iter: qacc / Ma / Jaref update", "iter: gauss terms",
+         "iter: J'f + cost", "iter: gradient", "iter: M^-1 grad", "iter: beta + search update", "solve tail / loop exit",
+         "euler: M^-1 rhs", "euler: integrate", "step: tables + state load + rtrunk", "step: reward / obs / traj / store"]
+NAMES += ["-"] * (40 - len(NAMES))
 
 
 def main():
@@ -27,7 +32,7 @@ def main():
     env = RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", _library=lib, **H.env_kwargs())
     st = env.reset(0)
     g = torch.Generator().manual_seed(0)
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 40)()
     env.step(st, torch.zeros(B, 30))
     torch.cuda.synchronize()
     lib.vnl_prof_read(buf)
@@ -43,7 +48,8 @@ def main():
     tot = float(sum(buf))
     print(f"B={B} steps={steps} ms/step={t0.elapsed_time(t1) / steps:.2f} (diagnostic build; read shares only)")
     for n, v in zip(NAMES, buf):
-        print(f"  {n:24s} {100.0 * v / tot:6.2f} %")
+        if v:
+            print(f"  {n:44s} {100.0 * v / tot:6.2f} %")
 
 
 if __name__ == "__main__":

@@ -92,13 +92,17 @@ VNL_HD float vnl_recip(float x) {
 // Diagnostic build only (-DVNL_PROFILE, csrc/build.py --profile): per-stage s_memtime stamps summed
 // into a __device__ array that no product code reads.  Never defined in the shipped library.
 #ifdef VNL_PROFILE
-#define VNL_NPROF 16
+#define VNL_NPROF 40
 __device__ unsigned long long g_vnl_prof[VNL_NPROF];
-#define VNL_PROF(i)                                       \
-  do {                                                    \
-    unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-    prof_[i] += t_ - last_;                               \
-    last_ = __builtin_amdgcn_s_memtime();                 \
+// lane 0 keeps the running sums in LDS (section "prof", reserved in this build only); slot VNL_NPROF = last stamp
+#define VNL_PROF(i)                                                      \
+  do {                                                                   \
+    if (lane == 0) {                                                     \
+      unsigned long long* p_ = (unsigned long long*)(s + L.prof);        \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
+      p_[i] += t_ - p_[VNL_NPROF];                                       \
+      p_[VNL_NPROF] = __builtin_amdgcn_s_memtime();                      \
+    }                                                                    \
   } while (0)
 #else
 #define VNL_PROF(i)
@@ -164,11 +168,18 @@ struct EnvWave {
   vreal* s;  // LDS
   unsigned e, lane;
 #ifdef VNL_PROFILE
-  mutable unsigned long long prof_[VNL_NPROF] = {0}, last_ = 0;
-  VNL_HD void prof_begin() const { last_ = __builtin_amdgcn_s_memtime(); }
+  VNL_HD void prof_begin() const {
+    if (lane == 0) {
+      unsigned long long* p_ = (unsigned long long*)(s + L.prof);
+      for (int i = 0; i < VNL_NPROF; i++) p_[i] = 0;
+      p_[VNL_NPROF] = __builtin_amdgcn_s_memtime();
+    }
+  }
   VNL_HD void prof_end() const {
-    if (lane == 0)
-      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], prof_[i]);
+    if (lane == 0) {
+      unsigned long long* p_ = (unsigned long long*)(s + L.prof);
+      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], p_[i]);
+    }
   }
 #else
   VNL_HD void prof_begin() const {}
@@ -433,6 +444,7 @@ struct EnvWave {
   // Expects cinert in pool[0..10 nbody) (turned into crb in place).
   VNL_HD void mass_matrix(vreal diag_scale) const {
     tree_accumulate(L.P, 10);
+    VNL_PROF(5);
     // f_i = crb[body(i)] * cdof_i for every dof, parked in the six CG vectors Ma .. qfrc_c (contiguous,
     // dead whenever M is built); then one lane per run of consecutive matrix ENTRIES (not per row: rows
     // have 1 .. max_depth+1 entries): M(i, j) = f_i . cdof_j.
@@ -460,6 +472,7 @@ struct EnvWave {
       }
     }
     VNL_SYNC();
+    VNL_PROF(6);
   }
 
   // In-place L'DL in MuJoCo's mj_factorM order.  For a fixed k the rows that get updated are the
@@ -618,6 +631,7 @@ struct EnvWave {
       ftime[q] = a < m.nv ? m.dof_ftime[a] : -1, fslot[q] = a < m.nv ? m.dof_fslot[a] : 0;
     }
     VNL_SYNC();
+    VNL_PROF(7);
     const int nsteps = with_loop ? m.fac_steps : 0;  // (false: diagnostic pricing of the load / store phases only)
     for (int step = 0; step < nsteps; step++) {
       int npub = 0;
@@ -700,6 +714,7 @@ struct EnvWave {
       VNL_WAVE_FENCE();
     }
     VNL_SYNC();
+    VNL_PROF(8);
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
@@ -713,6 +728,7 @@ struct EnvWave {
       }
     }
     VNL_SYNC();
+    VNL_PROF(9);
   }
 
   // L -> L^-1 in place from N L = I:  N(i,t) = -L(i,t) - sum_{0<u<t} N(i,u) L(anc_u(i), t-u).  Row i of
@@ -858,6 +874,7 @@ struct EnvWave {
     }
     VNL_SYNC();
     int cv = tree_prefix(start, start == X0 ? X1 : X0);  // == X1
+    VNL_PROF(2);
     int ca = X0;
     VNL_FOR(b, m.nbody) {  // own acceleration term: sum over the body's dofs of cdof_dot * qvel
       S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
@@ -887,6 +904,7 @@ struct EnvWave {
     }
     VNL_SYNC();
     tree_prefix_inplace(ca);
+    VNL_PROF(3);
     VNL_FOR(b, m.nbody) {  // cfrc overwrites cacc in place (each body only needs its own entries)
       if (b == 0) {
         st6(ca, S6{v3(0, 0, 0), v3(0, 0, 0)});
@@ -902,6 +920,7 @@ struct EnvWave {
     VNL_FOR(d, m.nv)
       s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - dot(ld6(L.cdof + 6 * d), ld6(ca + 6 * m.dof_body[d]));
     VNL_SYNC();
+    VNL_PROF(4);
     return cv;
   }
 
@@ -1260,6 +1279,7 @@ struct EnvWave {
       VNL_FOR(r, ne) s[L.Jaref + r] = s[L.jv + r];
     }
     VNL_SYNC();
+    VNL_PROF(14);
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
     vreal cost = constraint_force() + gauss;
     vreal prev_cost = INFINITY;
@@ -1274,7 +1294,7 @@ struct EnvWave {
       s[L.mv + d] = -s[L.grad + d];  // M search
     }
     VNL_SYNC();
-    VNL_PROF(6);
+    VNL_PROF(15);
 
     for (int it = 0; it < m.iterations; it++) {
       vreal improvement = (prev_cost - cost) / m.scale;
@@ -1283,7 +1303,9 @@ struct EnvWave {
       // ---- line search
       vreal smag = sqrt(vdot(L.search, L.search)) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
+      VNL_PROF(16);
       jac_mul(L.search, L.jv, false);
+      VNL_PROF(17);
       vreal qg1 = vreal(0.), qg2 = vreal(0.);
       VNL_FOR(d, nv) {
         vreal sd = s[L.search + d];
@@ -1291,22 +1313,25 @@ struct EnvWave {
         qg2 += sd * s[L.mv + d];
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
-      VNL_PROF(7);
+      VNL_PROF(18);
       vreal alpha = (m.nefc <= 5 * VNL_LANES) ? line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol)
                                               : line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol);
       VNL_FOR(d, nv) {
         s[L.qacc + d] += alpha * s[L.search + d];
         s[L.Ma + d] += alpha * s[L.mv + d];
       }
+      VNL_PROF(19);
       VNL_FOR(r, ne) s[L.Jaref + r] += alpha * s[L.jv + r];
       VNL_SYNC();
-      VNL_PROF(8);
+      VNL_PROF(20);
       // ---- constraint + gradient update
       vreal gp = vdot(L.grad, L.Mgrad);
       vreal g = vreal(0.);
       VNL_FOR(d, nv) g += (s[L.Ma + d] - s[L.smooth + d]) * (s[L.qacc + d] - s[L.qacc_smooth + d]);
       g = vnl_wave_sum(g);
+      VNL_PROF(21);
       vreal ncost = constraint_force() + vreal(0.5) * g;
+      VNL_PROF(22);
       prev_cost = cost, cost = ncost, gauss = vreal(0.5) * g;
       vreal d1 = vreal(0.);
       VNL_FOR(d, nv) {
@@ -1316,9 +1341,9 @@ struct EnvWave {
       }
       d1 = vnl_wave_sum(d1);
       VNL_SYNC();
-      VNL_PROF(9);
+      VNL_PROF(23);
       solve_inplace(L.tmp);
-      VNL_PROF(10);
+      VNL_PROF(24);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
       VNL_FOR(d, nv) {
@@ -1328,6 +1353,7 @@ struct EnvWave {
         s[L.mv + d] = -s[L.grad + d] + beta * s[L.mv + d];
       }
       VNL_SYNC();
+      VNL_PROF(25);
     }
   }
 
@@ -1372,18 +1398,18 @@ struct EnvWave {
     kinematics();
     VNL_PROF(0);
     body_inertias(true);
-    int cvel = bias_forces();
-    VNL_PROF(3);
-    mass_matrix(vreal(0.));
     VNL_PROF(1);
+    int cvel = bias_forces();
+    mass_matrix(vreal(0.));
     factor();
     mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
+    VNL_PROF(10);
     invert_factor();
-    VNL_PROF(2);
+    VNL_PROF(11);
     smooth_forces();
-    VNL_PROF(4);
+    VNL_PROF(12);
     make_constraint(cvel);
-    VNL_PROF(5);
+    VNL_PROF(13);
     for (int rep = 0; rep < m.dbg_count; rep++) {
       if (m.dbg_stage == 6) {
         jac_mul(L.qacc_smooth, L.jv, false);
@@ -1423,16 +1449,19 @@ struct EnvWave {
   // forward.euler + _advance; leaves qacc (warm start) in L.qacc and the new state in L.qpos/qvel/act
   VNL_HD void euler() const {
     const int nv = m.nv;
+    VNL_PROF(26);  // the tail of solve()
     VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
     VNL_SYNC();
-    VNL_PROF(11);
     if (m.eulerdamp) {
       body_inertias(false);
+      VNL_PROF(1);
       mass_matrix(m.dt);
       factor();
+      VNL_PROF(10);
       invert_factor();
-      VNL_PROF(12);
+      VNL_PROF(11);
       solve_inplace(L.tmp);
+      VNL_PROF(27);
     }
     VNL_FOR(i, m.nu) {
       if (m.act_tau[i] >= vreal(0.)) s[L.act + i] += s[L.actdot + i] * m.dt;
@@ -1457,7 +1486,7 @@ struct EnvWave {
       }
     }
     VNL_SYNC();
-    VNL_PROF(13);
+    VNL_PROF(28);
   }
 
   // ------------------------------------------------------------------ env glue
@@ -1627,6 +1656,7 @@ struct EnvWave {
     }
     VNL_SYNC();
     const vreal* gw = st.warm + (size_t)e * m.nv;
+    VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
       forward(f == 0 ? gw : s + L.qacc);
       euler();
@@ -1681,7 +1711,7 @@ struct EnvWave {
       st.cur_frame[e] = new_frame, st.sub_clip_frame[e] = new_sub;
       st.term_err[e] = rtrunk;
     }
-    VNL_PROF(14);
+    VNL_PROF(30);  // reward, termination, obs / traj, state store
     prof_end();
   }
 

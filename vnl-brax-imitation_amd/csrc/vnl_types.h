@@ -80,6 +80,7 @@ struct WsLayout {
   int P;
   int efc_D, Jaref, jv; /* = P, P + nefc, P + 2 nefc */
   int smooth, qacc_smooth, qacc, Ma, grad, Mgrad, search, mv, qfrc_c, tmp, tmp2;
+  int prof; /* diagnostic build (-DVNL_PROFILE) only: per-stage cycle sums kept by lane 0 */
   int con_r, con_t1;    /* 3 per contact / 3 per collidable geom */
   int tab_anc, tab_madr, tab_body, tab_jump, tab_lvl; /* 8/16-bit index tables staged in LDS */
   int act_list;         /* ncon bytes: contacts with D != 0, then their count (int) */
