@@ -1,6 +1,8 @@
 #!/bin/bash
 # Instruction counts per stage: PMC over the step kernel with VNL_DBG_REPEAT=stage:4 (stage 0 = base).
 set -e
+# needs the diagnostic library: python vnl-brax-imitation_amd/csrc/build.py --knobs (before gpurun)
+export VNL_LIB=$GRAFT_REPO_ROOT/vnl-brax-imitation_amd/csrc/libvnl_knobs.so
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_stage; mkdir -p $OUT
 for st in ${STAGES:-0 1 2 3 4 5 6 7 8 9 10 11 12 13}; do

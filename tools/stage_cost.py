@@ -12,7 +12,7 @@ NAMES = {1: "kin+inertia+M+factor+invert", 2: "kinematics", 3: "kin+inertia+M", 
 
 
 def run(stage, count):
-    env = dict(os.environ)
+    env = dict(os.environ, VNL_LIB=os.path.join(ROOT, "vnl-brax-imitation_amd", "csrc", "libvnl_knobs.so"))  # build.py --knobs
     if count:
         env["VNL_DBG_REPEAT"] = f"{stage}:{count}"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2",

@@ -11,16 +11,17 @@ DEPS = ["vnl_lib.hip", "vnl_policy.hip", "vnl_body.h", "vnl_types.h", "../../inc
 OUT = os.path.join(HERE, "libvnl.so")
 
 
-def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
-    """profile=True builds the DIAGNOSTIC library libvnl_prof.so (per-stage stamps, -DVNL_PROFILE);
-    it is only ever loaded by tools/stage_profile.py."""
-    out = os.path.join(HERE, "libvnl_prof.so") if profile else OUT
+def build(force: bool = False, verbose: bool = False, profile: bool = False, knobs: bool = False) -> str:
+    """profile=True builds the DIAGNOSTIC library libvnl_prof.so (per-stage stamps, -DVNL_PROFILE), only ever
+    loaded by tools/stage_profile.py; knobs=True builds libvnl_knobs.so (-DVNL_STAGE_KNOBS: the VNL_DBG_REPEAT
+    stage-repeat knob of tools/stage_cost.py / tools/pmc_stage.sh).  Neither is the product library."""
+    out = os.path.join(HERE, "libvnl_prof.so") if profile else (os.path.join(HERE, "libvnl_knobs.so") if knobs else OUT)
     newest = max(os.path.getmtime(os.path.join(HERE, d)) for d in DEPS)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
-          (["-DVNL_PROFILE"] if profile else []) + [os.path.join(HERE, s) for s in SOURCES]
+          (["-DVNL_PROFILE"] if profile else []) + (["-DVNL_STAGE_KNOBS"] if knobs else []) + [os.path.join(HERE, s) for s in SOURCES]
     cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -35,7 +36,7 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
     for line in r.stderr.splitlines():
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split()[0]
-        elif name and ("vnl_step_kernel" in name or "vnl_reset_kernel" in name) and not profile:
+        elif name and ("vnl_step_kernel" in name or "vnl_reset_kernel" in name) and not profile and not knobs:
             if "ScratchSize" in line and int(line.split("]:")[1].split()[0]) != 0:
                 bad.append(f"{name}: {line.split('remark:')[1].strip()}")
             if "Occupancy [waves/SIMD]" in line and int(line.split("]:")[1].split()[0]) < 2:
@@ -47,4 +48,4 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv, knobs="--knobs" in sys.argv))

@@ -603,8 +603,13 @@ struct EnvWave {
   // it (numerators + pivot) in an LDS scratch line; every proper ancestor row a of j then does
   // row_a[c] -= (row_j[a] / D_j) * row_j[c] on its registers, reading row_j as LDS broadcasts.  One
   // wave executes its LDS operations in order, so the scratch line needs no double buffering.
-  template <int NSET, int MAXD>
-  VNL_HD void factor_rows(bool with_loop = true) const {
+  // SOLVE: the matrix is only needed to solve ONE system (forward.euler's M + h diag(damping)): the right-hand
+  // side rides along as an extra column (L' w = rhs is eliminated by the very same updates), the factor is
+  // never stored, and x = L^-1 D^-1 w follows by a forward substitution over the depth: the rows of depth c
+  // publish their x once per leaf below them, every deeper row reads "its" ancestor's x at a static offset.
+  // Replaces factor + inversion + two sparse products for that system.
+  template <int NSET, int MAXD, bool SOLVE = false>
+  VNL_HD void factor_rows(bool with_loop = true, int rhs = 0) const {
     static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
     constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
     vreal rr[NSET][MAXD], dg[NSET];
@@ -625,10 +630,15 @@ struct EnvWave {
     // [row numerators (MAXD) | 1/pivot | j | pad], so the chain of dependent steps is the tree height.
     constexpr int LW = MAXD + 4;
     int ftime[NSET], fslot[NSET];
+    vreal bb[NSET], myinv[NSET];  // SOLVE only
+    int leaf[NSET], lmask[NSET];
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1, fslot[q] = a < m.nv ? m.dof_fslot[a] : 0;
+      const int pack = a < m.nv ? m.dof_fslot[a] : 0;
+      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1, fslot[q] = pack & 0xff;
+      leaf[q] = (pack >> 8) & 0xff, lmask[q] = pack >> 16;
+      bb[q] = (SOLVE && a < m.nv) ? s[rhs + a] : vreal(0.), myinv[q] = vreal(0.);
     }
     VNL_SYNC();
     VNL_PROF(7);
@@ -651,7 +661,12 @@ struct EnvWave {
           vreal inv = vnl_recip(dg[q]);
           s[line + MAXD] = inv;
           s[line + MAXD + 1] = vreal(a);  // exact: a < 2^24
-          s[L.dinv + a] = inv;
+          if constexpr (SOLVE) {
+            s[line + MAXD + 2] = bb[q];
+            myinv[q] = inv;
+          } else {
+            s[L.dinv + a] = inv;
+          }
         }
       }
       VNL_WAVE_FENCE();
@@ -708,10 +723,37 @@ struct EnvWave {
               }
             }
             dg[q] -= t * traw;
+            if constexpr (SOLVE) bb[q] -= t * line[MAXD + 2];
           }
         }
       }
       VNL_WAVE_FENCE();
+    }
+    if constexpr (SOLVE) {
+      VNL_SYNC();
+      const int xs = sc;  // [leaf][MAXD] published x values; the scratch lines are no longer needed
+      vreal acc[NSET];
+#pragma unroll
+      for (int q = 0; q < NSET; q++) acc[q] = bb[q] * myinv[q];  // D^-1 w
+#pragma unroll
+      for (int c = 0; c < MAXD; c++) {
+        if (c <= m.max_depth) {
+#pragma unroll
+          for (int q = 0; q < NSET; q++) {
+            int a = (int)lane + q * VNL_LANES;
+            if (a < m.nv && dep[q] == c) {  // final: all ancestor terms are in
+              s[rhs + a] = acc[q];
+              for (int mk = lmask[q]; mk != 0; mk &= mk - 1) s[xs + __builtin_ctz(mk) * MAXD + c] = acc[q];
+            }
+          }
+          VNL_WAVE_FENCE();
+#pragma unroll
+          for (int q = 0; q < NSET; q++)
+            if (dep[q] > c) acc[q] -= rr[q][c] * myinv[q] * s[xs + leaf[q] * MAXD + c];
+        }
+      }
+      VNL_SYNC();
+      return;
     }
     VNL_SYNC();
     VNL_PROF(8);
@@ -776,6 +818,18 @@ struct EnvWave {
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36>(with_loop);
     else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_2, 36>(with_loop);
     else factor_lds();
+  }
+  // solve (matrix in LD) x = s[rhs .. rhs+nv) in place without storing a factor; false if this model needs the
+  // general route (factor + invert_factor + solve_inplace)
+  VNL_HD bool factor_solve(int rhs) const {
+    const int nv = m.nv, md = m.max_depth;
+    const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
+    if (m.fac_nleaf == 0) return false;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16, true>(true, rhs);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36, true>(true, rhs);
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_2, 36, true>(true, rhs);
+    else return false;
+    return true;
   }
   VNL_HD void invert_factor() const {
     const int nv = m.nv, md = m.max_depth;
@@ -1366,6 +1420,7 @@ struct EnvWave {
     // Timing knob (VNL_DBG_REPEAT=stage:count at env creation; 0 in normal use): run one stage
     // `count` extra times on data that is recomputed afterwards, so results are unchanged and the
     // wall-time difference prices that stage in the real (uninstrumented) build.
+#ifdef VNL_STAGE_KNOBS  // diagnostic library only (csrc/build.py --knobs): five extra inlined copies of the stages
     for (int rep = 0; rep < m.dbg_count; rep++) {
       if (m.dbg_stage == 1) {
         kinematics();
@@ -1395,6 +1450,7 @@ struct EnvWave {
         factor(false);
       }
     }
+#endif
     kinematics();
     VNL_PROF(0);
     body_inertias(true);
@@ -1410,6 +1466,7 @@ struct EnvWave {
     VNL_PROF(12);
     make_constraint(cvel);
     VNL_PROF(13);
+#ifdef VNL_STAGE_KNOBS
     for (int rep = 0; rep < m.dbg_count; rep++) {
       if (m.dbg_stage == 6) {
         jac_mul(L.qacc_smooth, L.jv, false);
@@ -1443,6 +1500,7 @@ struct EnvWave {
         if (p.cost == vreal(-1.)) s[L.tmp] = p.cost;
       }
     }
+#endif
     solve();
   }
 
@@ -1456,11 +1514,11 @@ struct EnvWave {
       body_inertias(false);
       VNL_PROF(1);
       mass_matrix(m.dt);
-      factor();
-      VNL_PROF(10);
-      invert_factor();
-      VNL_PROF(11);
-      solve_inplace(L.tmp);
+      if (!factor_solve(L.tmp)) {
+        factor();
+        invert_factor();
+        solve_inplace(L.tmp);
+      }
       VNL_PROF(27);
     }
     VNL_FOR(i, m.nu) {

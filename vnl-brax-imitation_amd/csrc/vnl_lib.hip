@@ -341,6 +341,20 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     for (int j = nv - 1; j >= 0; j--)
       if (par[j] >= 0 && ftime[par[j]] <= ftime[j]) return fail(VNL_ERR_UNSUPPORTED, "factorisation schedule is not causal");
     d.fac_steps = (int)count.size();
+    {  // leaves of the dof tree, for the forward substitution of factor_rows<.., true>
+      std::vector<int> leaf_id(nv, -1);
+      int nleaf = 0;
+      for (int j = 0; j < nv; j++)
+        if (ndesc[j] == 0) leaf_id[j] = nleaf++;
+      d.fac_nleaf = nleaf <= VNL_FAC_LINES ? nleaf : 0;
+      if (d.fac_nleaf)
+        for (int a = 0; a < nv; a++) {
+          int mask = 0;
+          for (int j = a; j <= a + ndesc[a]; j++)
+            if (leaf_id[j] >= 0) mask |= 1 << leaf_id[j];
+          fslot[a] |= (leaf_id[a + ndesc[a]] << 8) | (mask << 16);  // the last descendant is a leaf
+        }
+    }
     UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))

@@ -22,6 +22,7 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
   int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
   int fac_steps; /* number of steps of the factorisation schedule */
+  int fac_nleaf; /* leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand side), else 0 */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
@@ -42,7 +43,7 @@ struct DevModel {
   // dofs; tree-sparse qM layout (MuJoCo dof_Madr order: self, parent, grandparent, ...)
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
-  const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot, and its scratch line */
+  const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot; scratch line | one leaf under a << 8 | mask of all leaves under a << 16 */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
   const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
   const vreal *dof_armature, *dof_damping;
