@@ -21,7 +21,8 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, kno
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
-          (["-DVNL_PROFILE"] if profile else []) + (["-DVNL_STAGE_KNOBS"] if knobs else []) + [os.path.join(HERE, s) for s in SOURCES]
+          (["-DVNL_PROFILE"] if profile else []) + (["-DVNL_STAGE_KNOBS"] if knobs else []) + \
+          os.environ.get("VNL_HIPCC_EXTRA", "").split() + [os.path.join(HERE, s) for s in SOURCES]
     cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
