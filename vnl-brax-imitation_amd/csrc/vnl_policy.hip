@@ -20,7 +20,7 @@
 #include "../../include/vnl.h"
 
 #define PT 32          /* envs per workgroup */
-#define PTHREADS 256   /* 4 waves */
+#define PTHREADS 1024  /* 16 waves: four per SIMD, some compute while the others wait for their weight loads */
 #define LN_EPS 1e-6f   /* flax.linen.LayerNorm default */
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -83,7 +83,8 @@ __device__ __forceinline__ void dense_tile(const float* X, int ldx, int K, const
 __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const float* __restrict__ g,
                                                 const float* __restrict__ be) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave * 8; r < wave * 8 + 8; r++) {
+  constexpr int RPW = PT / (PTHREADS / 64);  // rows per wave
+  for (int r = wave * RPW; r < wave * RPW + RPW; r++) {
     float* y = Y + r * ldy;
     float s = 0.f, ss = 0.f;
     for (int c = lane; c < N; c += 64) {
