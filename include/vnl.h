@@ -160,7 +160,11 @@ int64_t vnl_policy_num_params(const vnl_policy*);
 int vnl_policy_forward(vnl_policy*, const float* params, const float* obs_mean, const float* obs_std,
                        const float* traj, const float* obs, const float* eps_latent, const float* eps_action,
                        int32_t batch, int32_t deterministic, float* action, float* raw_action, float* log_prob,
-                       float* logits, float* latent_mean, float* latent_logvar, void* stream);
+                       float* logits, float* latent_mean, float* latent_logvar,
+                       const float* rand_action /* [act] pre-tanh action or NULL */,
+                       float* rand_log_prob /* [batch] its log-prob under every env's distribution
+                                               (the reference's policy extras, ppo_networks.py:67-73), or NULL */,
+                       void* stream);
 
 /* ---- rollout post-processing: the training wrappers and the Transition logging in ONE launch ----
  * brax EpisodeWrapper + AutoResetWrapper as applied by the reference's wrap_for_training

@@ -61,3 +61,6 @@ def test_make_policy_uses_hip_kernel_on_gpu():
     a2, e2 = pol_torch(traj, obs, torch.Generator(device=dev).manual_seed(5))
     assert set(e1) == set(e2) == {"log_prob", "rand_log_prob", "raw_action", "logits"}
     assert torch.allclose(e1["logits"], e2["logits"], atol=2e-4) and torch.allclose(a1, a2, atol=2e-4)
+    # same generator, same draw order: the kernel's rand_log_prob is that of the same random action
+    assert torch.allclose(e1["rand_log_prob"], e2["rand_log_prob"], atol=5e-3, rtol=2e-4)
+    assert torch.allclose(e1["log_prob"], e2["log_prob"], atol=5e-3, rtol=2e-4)

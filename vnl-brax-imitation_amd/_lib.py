@@ -134,7 +134,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
         lib.vnl_policy_destroy.restype = None
         lib.vnl_policy_num_params.argtypes = [vp]
         lib.vnl_policy_num_params.restype = C.c_int64
-        lib.vnl_policy_forward.argtypes = [vp] + [vp] * 7 + [C.c_int32, C.c_int32] + [vp] * 6 + [vp]
+        lib.vnl_policy_forward.argtypes = [vp] + [vp] * 7 + [C.c_int32, C.c_int32] + [vp] * 6 + [vp, vp] + [vp]
     return lib
 
 

@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
                                                               int deterministic, float* __restrict__ action,
                                                               float* __restrict__ raw_action, float* __restrict__ log_prob,
                                                               float* __restrict__ logits, float* __restrict__ lat_mean,
-                                                              float* __restrict__ lat_logvar) {
+                                                              float* __restrict__ lat_logvar,
+                                                              const float* __restrict__ rand_action,
+                                                              float* __restrict__ rand_log_prob) {
   extern __shared__ __align__(16) float lds[];
   float* A = lds;
   float* B = lds + PT * p.ldA;
@@ -201,6 +203,10 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
         raw_action[g] = raw, action[g] = tanhf(raw);
         // Normal log-pdf minus the tanh log-det-Jacobian 2 (log 2 - x - softplus(-2x))
         term = -0.5f * eps * eps - 0.9189385332046727f - logf(scale) - 2.f * (0.6931471805599453f - raw - softplusf(-2.f * raw));
+        if (rand_action) {  // log-prob of ONE random pre-tanh action shared by all envs (ppo_networks.py:67-73)
+          float x = rand_action[c], z = (x - loc) / scale;
+          lp[r * ldy + na + c] = -0.5f * z * z - 0.9189385332046727f - logf(scale) - 2.f * (0.6931471805599453f - x - softplusf(-2.f * x));
+        }
       }
     }
     lp[r * ldy + c] = term;
@@ -210,6 +216,11 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     float s = 0.f;
     for (int c = 0; c < na; c++) s += lp[tid * ldy + c];
     log_prob[e0 + tid] = s;
+    if (rand_action) {
+      float s2 = 0.f;
+      for (int c = 0; c < na; c++) s2 += lp[tid * ldy + na + c];
+      rand_log_prob[e0 + tid] = s2;
+    }
   }
 }
 
@@ -312,17 +323,20 @@ extern "C" int64_t vnl_policy_num_params(const vnl_policy* p) { return p ? p->np
 extern "C" int vnl_policy_forward(vnl_policy* p, const float* params, const float* obs_mean, const float* obs_std,
                                   const float* traj, const float* obs, const float* eps_latent, const float* eps_action,
                                   int32_t batch, int32_t deterministic, float* action, float* raw_action, float* log_prob,
-                                  float* logits, float* latent_mean, float* latent_logvar, void* stream) {
+                                  float* logits, float* latent_mean, float* latent_logvar, const float* rand_action,
+                                  float* rand_log_prob, void* stream) {
   if (!p || !params || !traj || !obs || !eps_latent || !action || !logits || !latent_mean || !latent_logvar)
     return pfail(VNL_ERR_ARG, "vnl_policy_forward: null argument");
   if (!deterministic && (!eps_action || !raw_action || !log_prob))
     return pfail(VNL_ERR_ARG, "vnl_policy_forward: stochastic mode needs eps_action, raw_action, log_prob");
+  if ((rand_action == nullptr) != (rand_log_prob == nullptr) || (rand_action && deterministic))
+    return pfail(VNL_ERR_ARG, "rand_action / rand_log_prob: both or neither, stochastic mode only");
   if ((obs_mean == nullptr) != (obs_std == nullptr)) return pfail(VNL_ERR_ARG, "obs_mean / obs_std must both be given or both null");
   if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
   int grid = (batch + PT - 1) / PT;
   hipLaunchKernelGGL(vnl_policy_kernel, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
                      obs_mean, obs_std, traj, obs, eps_latent, eps_action, (int)batch, (int)deterministic, action,
-                     raw_action, log_prob, logits, latent_mean, latent_logvar);
+                     raw_action, log_prob, logits, latent_mean, latent_logvar, rand_action, rand_log_prob);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pfail(VNL_ERR_HIP, hipGetErrorString(e));
   return VNL_OK;

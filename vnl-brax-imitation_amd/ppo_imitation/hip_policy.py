@@ -42,7 +42,7 @@ class HipIntentionPolicy:
     @torch.no_grad()
     def forward(self, params: torch.Tensor, obs_mean: Optional[torch.Tensor], obs_std: Optional[torch.Tensor],
                 traj: torch.Tensor, obs: torch.Tensor, eps_latent: torch.Tensor, eps_action: Optional[torch.Tensor],
-                deterministic: bool = False) -> Tuple[torch.Tensor, dict]:
+                deterministic: bool = False, rand_action: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, dict]:
         B, na, nl = obs.shape[0], self.action_size, self.net.latents
         f32 = dict(dtype=torch.float32, device=obs.device)
         c = lambda t: t.contiguous()  # noqa: E731
@@ -52,6 +52,11 @@ class HipIntentionPolicy:
         lat_mean, lat_logvar = torch.empty((B, nl), **f32), torch.empty((B, nl), **f32)
         raw = torch.empty((B, na), **f32) if not deterministic else None
         lp = torch.empty((B,), **f32) if not deterministic else None
+        rlp = torch.empty((B,), **f32) if (rand_action is not None and not deterministic) else None
+        if rlp is None:
+            rand_action = None
+        else:
+            rand_action = c(rand_action)
         if not deterministic:
             eps_action = c(eps_action)
         if obs_mean is not None:
@@ -60,7 +65,10 @@ class HipIntentionPolicy:
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
         _lib.check(self.lib, self.lib.vnl_policy_forward(
             self.h, p(params), p(obs_mean), p(obs_std), p(traj), p(obs), p(eps_latent), p(eps_action), B,
-            int(deterministic), p(action), p(raw), p(lp), p(logits), p(lat_mean), p(lat_logvar), stream))
-        self._hold = (traj, obs, eps_latent, eps_action, params, obs_mean, obs_std)
+            int(deterministic), p(action), p(raw), p(lp), p(logits), p(lat_mean), p(lat_logvar), p(rand_action),
+            p(rlp), stream))
+        self._hold = (traj, obs, eps_latent, eps_action, params, obs_mean, obs_std, rand_action)
         extras = {} if deterministic else {"log_prob": lp, "raw_action": raw, "logits": logits}
+        if rlp is not None:
+            extras["rand_log_prob"] = rlp
         return action, {**extras, "latent_mean": lat_mean, "latent_logvar": lat_logvar}

@@ -112,6 +112,14 @@ def _randn(shape, key: Optional[torch.Generator], device) -> torch.Tensor:
     return torch.randn(shape, generator=key, dtype=torch.float32, device=device)
 
 
+def _rand_action(n: int, key: Optional[torch.Generator], device) -> torch.Tensor:
+    """One U(-1, 1) pre-tanh action shared by the whole batch (ppo_networks.py:67-69), drawn on the device the
+    generator lives on (a host draw + copy would synchronise the rollout loop every step)."""
+    if key is not None and key.device.type != torch.device(device).type:
+        return (torch.rand((n,), generator=key) * 2 - 1).to(device)
+    return torch.rand((n,), generator=key, device=device) * 2 - 1
+
+
 def make_inference_fn(ppo_networks: PPOImitationNetworks):
     """ppo_networks.py:35-87.  `key_sample` is a torch.Generator (or None for the global one);
     the JAX threefry stream is not reproduced, the sampling structure is:
@@ -143,13 +151,11 @@ def make_inference_fn(ppo_networks: PPOImitationNetworks):
             mean = std = None
             if ppo_networks.normalizes and normalizer_params is not None:
                 mean, std = normalizer_params.mean, normalizer_params.std
+            random_actions = None if deterministic else _rand_action(dist.event_size, key_sample, dev)
             action, extras = hip_cache[k].forward(policy_params.detach(), mean, std, trajectories, observations,
-                                                  eps_latent, eps_action, deterministic)
+                                                  eps_latent, eps_action, deterministic, rand_action=random_actions)
             if deterministic:
                 return action, {}
-            u = torch.rand((dist.event_size,), generator=key_sample if (key_sample is None or key_sample.device.type == "cpu") else None)
-            random_actions = (u * 2 - 1).to(dev)
-            extras["rand_log_prob"] = dist.log_prob(extras["logits"], random_actions.expand_as(extras["raw_action"]))
             return action, {k2: extras[k2] for k2 in ("log_prob", "rand_log_prob", "raw_action", "logits")}
 
         if use_hip:
@@ -168,8 +174,7 @@ def make_inference_fn(ppo_networks: PPOImitationNetworks):
             eps_action = _randn((*lead, dist.event_size), key_sample, dev)
             raw_actions = dist.sample_no_postprocessing(logits, eps_action)
             log_prob = dist.log_prob(logits, raw_actions)
-            u = torch.rand((dist.event_size,), generator=key_sample if (key_sample is None or key_sample.device.type == "cpu") else None)
-            random_actions = (u * 2 - 1).to(dev)
+            random_actions = _rand_action(dist.event_size, key_sample, dev)
             rand_log_prob = dist.log_prob(logits, random_actions.expand_as(raw_actions))
             return dist.postprocess(raw_actions), {
                 "log_prob": log_prob,
