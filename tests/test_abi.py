@@ -62,3 +62,24 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"import\s+oracle|from\s+oracle|oracle[/.]oracle|liborc|vnl_oracle|orc_", txt), \
                     os.path.join(dp, f)
+
+
+def test_argument_validation_of_the_helper_entry_points():
+    """vnl_rollout_post / vnl_ppo_head / vnl_policy_forward reject malformed descriptors with an error code and a
+    message instead of launching (checked on the product library: validation happens before any HIP call)."""
+    lib = _lib.load_library()
+    d = _lib.PostDesc()
+    assert lib.vnl_rollout_post(C.byref(d), 4, None) == -1 and b"null" in lib.vnl_last_error()
+    d.done = C.c_void_p(8)  # never dereferenced: validation fails first
+    d.num_ops = _lib.POST_MAX_OPS + 1
+    assert lib.vnl_rollout_post(C.byref(d), 4, None) == -1 and b"too many" in lib.vnl_last_error()
+    d.num_ops = 1  # op 0 has no source
+    assert lib.vnl_rollout_post(C.byref(d), 4, None) == -1 and b"bad op" in lib.vnl_last_error()
+    assert lib.vnl_rollout_post(None, 4, None) == -1
+    a = _lib.PPOHeadArgs()
+    work = C.c_void_p(8)
+    assert lib.vnl_ppo_head(C.byref(a), work, None) == -1 and b"sizes" in lib.vnl_last_error()
+    a.T, a.B, a.act, a.latent = 2, 2, 3, 4
+    assert lib.vnl_ppo_head(C.byref(a), work, None) == -1 and b"null buffer" in lib.vnl_last_error()
+    assert lib.vnl_policy_forward(None, None, None, None, None, None, None, None, 1, 0, None, None, None, None, None,
+                                  None, None, None, None) == -1
