@@ -213,6 +213,14 @@ typedef struct vnl_ppo_head_args {
 #define VNL_PPO_HEAD_WORKSPACE_FLOATS (4 + 4 * 256)
 int vnl_ppo_head(const vnl_ppo_head_args*, float* workspace, void* stream);
 
+/* ---- Adam on one flat buffer (optax.adam as the reference builds it, ppo_imitation/train.py:231-233:
+ * b1 0.9, b2 0.999, eps 1e-8, no weight decay): mu, nu, params updated in place in ONE launch.
+ * `count` is the device-resident step number AFTER this step (the caller increments it first), so that
+ * the launch can sit inside a captured hipGraph. */
+int vnl_adam_step(float* params, const float* grads, float* mu, float* nu, const int64_t* count, int64_t n,
+                  double lr, double b1, double b2, double eps, void* stream); /* hyper-parameters as the Python doubles they are:
+                  1 - b2 is formed in double before the cast to float32, as optax does */
+
 #ifdef __cplusplus
 }
 #endif

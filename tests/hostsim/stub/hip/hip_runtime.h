@@ -45,6 +45,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_PREFIX_PER_LANE 512
 #define VNL_ROWSETS_1 64
 #define VNL_POST_THREADS 1
+#define VNL_ADAM_THREADS 1
 #define VNL_HEAD_THREADS 1
 #define VNL_HEAD_GROUP 1
 #define VNL_GROUP_SUM(v) (void)(v)

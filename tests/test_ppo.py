@@ -224,3 +224,22 @@ def test_fused_loss_head_matches_autograd_gpu(nets):
 
     n, pf, vf = nets
     _check_head(_loss_both_ways(n, pf, vf, torch.device("cuda:0"), _lib.load_library(), B=128, T=20))
+
+
+def test_adam_kernel_matches_the_torch_update():
+    """vnl_adam_step (one launch) against FlatAdam's op-by-op update (optax.adam semantics), host simulation."""
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(1000, generator=g)
+    outs = []
+    for lib in (None, H.hostsim_library("float")):
+        opt = ppo.FlatAdam(3e-3, lib=lib)
+        p, st = p0.clone(), None
+        st = opt.init(p)
+        gg = torch.Generator().manual_seed(1)
+        for _ in range(5):
+            opt.update(torch.randn(1000, generator=gg) * 0.1, st, p)
+        outs.append((p, st))
+    (pa, sa), (pb, sb) = outs
+    assert int(sa["count"]) == int(sb["count"]) == 5
+    assert torch.allclose(pa, pb, rtol=0, atol=2e-7) and torch.allclose(sa["nu"], sb["nu"], rtol=1e-6, atol=0)
+    assert not torch.equal(pa, p0)

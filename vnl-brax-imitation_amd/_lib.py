@@ -103,7 +103,7 @@ PPO_HEAD_WORKSPACE_FLOATS = 4 + 4 * 256
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
     "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
-    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head",
+    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step",
 )
 
 
@@ -128,6 +128,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.vnl_rollout_post.argtypes = [C.POINTER(PostDesc), C.c_int32, vp]
     lib.vnl_ppo_head.argtypes = [C.POINTER(PPOHeadArgs), vp, vp]
+    lib.vnl_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int64] + [C.c_double] * 4 + [vp]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
         lib.vnl_policy_destroy.argtypes = [vp]

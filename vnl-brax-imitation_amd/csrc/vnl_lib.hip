@@ -828,4 +828,35 @@ extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* 
   return VNL_OK;
 }
 
+// ---- Adam (include/vnl.h: vnl_adam_step) ----------------------------------------------------------
+#ifndef VNL_ADAM_THREADS
+#define VNL_ADAM_THREADS 256
+#endif
+__global__ void __launch_bounds__(VNL_ADAM_THREADS) vnl_adam_kernel(float* p, const float* g, float* mu, float* nu,
+                                                                    const long long* count, long long n, double lr_,
+                                                                    double b1_, double b2_, double eps_) {
+  const double t = (double)count[0];
+  const float bc1 = (float)(1.0 - pow(b1_, t)), bc2 = (float)(1.0 - pow(b2_, t));
+  const float b1 = (float)b1_, b2 = (float)b2_, omb1 = (float)(1.0 - b1_), omb2 = (float)(1.0 - b2_);
+  const float lr = (float)lr_, eps = (float)eps_;
+  for (long long i = (long long)blockIdx.x * VNL_ADAM_THREADS + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VNL_ADAM_THREADS) {
+    const float gi = g[i];
+    const float m = b1 * mu[i] + omb1 * gi, v = b2 * nu[i] + omb2 * gi * gi;
+    mu[i] = m, nu[i] = v;
+    p[i] -= lr * ((m / bc1) / (sqrtf(v / bc2) + eps));
+  }
+}
+
+extern "C" int vnl_adam_step(float* params, const float* grads, float* mu, float* nu, const int64_t* count, int64_t n,
+                             double lr, double b1, double b2, double eps, void* stream) {
+  if (!params || !grads || !mu || !nu || !count || n <= 0) return fail(VNL_ERR_ARG, "vnl_adam_step: null argument");
+  long long blocks = (n + VNL_ADAM_THREADS - 1) / VNL_ADAM_THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vnl_adam_kernel, dim3((unsigned)blocks), dim3(VNL_ADAM_THREADS), 0, (hipStream_t)stream, params,
+                     grads, mu, nu, (const long long*)count, (long long)n, lr, b1, b2, eps);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
 // the policy-forward entry points (vnl_policy_*) live in vnl_policy.hip

@@ -44,8 +44,8 @@ class TrainingState:
 class FlatAdam:
     """optax.adam(lr) [UPSTREAM] on one flat buffer: b1=0.9, b2=0.999, eps=1e-8, no weight decay."""
 
-    def __init__(self, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
-        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+    def __init__(self, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8, lib=None):
+        self.lr, self.b1, self.b2, self.eps, self.lib = lr, b1, b2, eps, lib
 
     def init(self, params: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {"mu": torch.zeros_like(params), "nu": torch.zeros_like(params),
@@ -53,8 +53,25 @@ class FlatAdam:
 
     @torch.no_grad()
     def update(self, grads: torch.Tensor, state: Dict[str, torch.Tensor], params: torch.Tensor) -> None:
-        """No host read-back (the step count stays on the device), so the update can sit inside a hipGraph."""
+        """No host read-back (the step count stays on the device), so the update can sit inside a hipGraph.
+        On a HIP device (or with `self.lib` set) the update itself is one launch of vnl_adam_step."""
         state["count"] += 1
+        lib = self.lib
+        if lib is None and params.is_cuda:
+            from .. import _lib
+
+            lib = self.lib = _lib.load_library()
+        if lib is not None and params.dtype == torch.float32 and params.is_contiguous() and grads.is_contiguous():
+            import ctypes as C
+
+            from .. import _lib
+
+            ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            stream = C.c_void_p(torch.cuda.current_stream(params.device).cuda_stream) if params.is_cuda else C.c_void_p(0)
+            _lib.check(lib, lib.vnl_adam_step(ptr(params), ptr(grads), ptr(state["mu"]), ptr(state["nu"]),
+                                              ptr(state["count"]), params.numel(), self.lr, self.b1, self.b2, self.eps,
+                                              stream))
+            return
         t = state["count"].to(torch.float64)
         bc1 = (1 - torch.pow(torch.full_like(t, self.b1), t)).to(params.dtype)
         bc2 = (1 - torch.pow(torch.full_like(t, self.b2), t)).to(params.dtype)
