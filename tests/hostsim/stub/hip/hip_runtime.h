@@ -47,6 +47,8 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_POST_THREADS 1
 #define VNL_ADAM_THREADS 1
 #define VNL_HEAD_THREADS 1
+#define VNL_FINISH_THREADS 1
+#define VNL_FINISH_SUM(v) (void)(v)
 #define VNL_HEAD_GROUP 1
 #define VNL_GROUP_SUM(v) (void)(v)
 #define __shared__

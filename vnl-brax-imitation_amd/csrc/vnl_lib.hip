@@ -679,6 +679,11 @@ extern "C" int vnl_rollout_post(const vnl_post_desc* desc, int32_t num_envs, voi
   (v += __shfl_xor(v, 16, 32), v += __shfl_xor(v, 8, 32), v += __shfl_xor(v, 4, 32), v += __shfl_xor(v, 2, 32), v += __shfl_xor(v, 1, 32))
 #endif
 #define VNL_HEAD_MAXBLK 256
+#ifndef VNL_FINISH_THREADS
+#define VNL_FINISH_THREADS 64
+#define VNL_FINISH_SUM(v) \
+  (v += __shfl_xor(v, 32), v += __shfl_xor(v, 16), v += __shfl_xor(v, 8), v += __shfl_xor(v, 4), v += __shfl_xor(v, 2), v += __shfl_xor(v, 1))
+#endif
 __device__ __forceinline__ float vnl_block_sum(float v, float* red) {
   const unsigned tid = threadIdx.x;
   __syncthreads();
@@ -799,10 +804,13 @@ __global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_head_kernel(vnl_ppo_
 }
 
 __global__ void vnl_ppo_finish_kernel(vnl_ppo_head_args a, const float* stats, int nblk) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one 64-lane wave: lane l sums partials l, l+64, ... (fixed order), then a shuffle tree
+  const int lane = (int)threadIdx.x;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < nblk; b++)
+  for (int b = lane; b < nblk; b += VNL_FINISH_THREADS)
     for (int k = 0; k < 4; k++) s[k] += stats[4 + 4 * b + k];
+  for (int k = 0; k < 4; k++) VNL_FINISH_SUM(s[k]);
+  if (lane != 0) return;
   const int N = a.T * a.B;
   const float inv_n = 1.f / (float)N, kscale = a.kl_weight / (float)(N * a.latent);
   const float pl = s[0] * inv_n, vl = 0.25f * s[1] * inv_n, el = -a.entropy_cost * s[2] * inv_n, kl = -0.5f * kscale * s[3];
@@ -823,7 +831,7 @@ extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* 
   if (nblk > VNL_HEAD_MAXBLK) nblk = VNL_HEAD_MAXBLK;
   hipLaunchKernelGGL(vnl_ppo_gae_kernel, dim3(1), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
   hipLaunchKernelGGL(vnl_ppo_head_kernel, dim3(nblk), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
-  hipLaunchKernelGGL(vnl_ppo_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *a, (const float*)workspace, nblk);
+  hipLaunchKernelGGL(vnl_ppo_finish_kernel, dim3(1), dim3(VNL_FINISH_THREADS), 0, (hipStream_t)stream, *a, (const float*)workspace, nblk);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

@@ -121,6 +121,7 @@ def compute_ppo_intention_loss(
     kl_weight: float = 1e-4,
     noise: Optional[Dict[str, torch.Tensor]] = None,
     head: Any = "auto",
+    time_major: bool = False,
 ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """intention_losses.py:91-202.  `data` has leading dims [B, T]; `noise` optionally supplies the
     two Gaussian draws ('latent' [T,B,latent], 'entropy' [T,B,act]) for reproducible tests.
@@ -130,7 +131,8 @@ def compute_ppo_intention_loss(
     policy_apply = ppo_network.policy_network.apply
     value_apply = ppo_network.value_network.apply
 
-    data = data.map(lambda x: x.transpose(0, 1))  # time-major, :131
+    if not time_major:  # (the trainer's captured step hands over [T, B, ...] directly: no strided copies)
+        data = data.map(lambda x: x.transpose(0, 1))  # time-major, :131
     obs = data.observation
     dev = obs.device
     T, B = obs.shape[:2]

@@ -51,13 +51,14 @@ class ValueMLP:
         return flat
 
     def apply(self, flat: torch.Tensor, obs: torch.Tensor) -> torch.Tensor:
-        x = obs
+        lead = obs.shape[:-1]
+        x = obs.reshape(-1, obs.shape[-1])
         n = len(self.sizes)
-        for i in range(n):
-            x = x @ self.layout.view(flat, f"hidden_{i}/kernel") + self.layout.view(flat, f"hidden_{i}/bias")
+        for i in range(n):  # addmm: bias fused into the GEMM epilogue
+            x = torch.addmm(self.layout.view(flat, f"hidden_{i}/bias"), x, self.layout.view(flat, f"hidden_{i}/kernel"))
             if i != n - 1:
                 x = F.silu(x)
-        return x.squeeze(-1)
+        return x.reshape(*lead, -1).squeeze(-1)
 
 
 @dataclasses.dataclass

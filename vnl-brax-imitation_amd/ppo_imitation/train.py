@@ -226,7 +226,7 @@ def train(
         n, T = data.reward.shape[:2]
         mb = n // num_minibatches
         g = graphed
-        g["full"] = data.map(torch.clone)
+        g["full"] = data.map(lambda x: x.transpose(0, 1).contiguous())  # time-major [T, N, ...]: gathers along dim 1
         g["idx"] = torch.zeros(mb, dtype=torch.int64, device=device)
         g["norm"] = normalizer_params.clone()
         g["noise"] = {"latent": torch.zeros(T, mb, ppo_network.policy_module.latents, device=device),
@@ -238,12 +238,12 @@ def train(
         def body():
             full, idx = g["full"], g["idx"]
             mbd = acting.Transition(
-                full.observation.index_select(0, idx), full.action.index_select(0, idx),
-                full.reward.index_select(0, idx), full.discount.index_select(0, idx),
-                full.next_observation[:, -1:].index_select(0, idx),  # only the bootstrap row is read
-                {k: {kk: vv.index_select(0, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
+                full.observation.index_select(1, idx), full.action.index_select(1, idx),
+                full.reward.index_select(1, idx), full.discount.index_select(1, idx),
+                full.next_observation[-1:].index_select(1, idx),  # only the bootstrap row is read
+                {k: {kk: vv.index_select(1, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
             leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
-            loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"])
+            loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"], time_major=True)
             loss.backward()
             leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
             if dist is None:
@@ -328,7 +328,7 @@ def train(
             if not graphed:
                 build_graphed(data, normalizer_params)
             for dst, src in zip(acting._leaves(graphed["full"]), acting._leaves(data)):
-                dst.copy_(src)
+                dst.copy_(src.transpose(0, 1))
             for f in ("count", "mean", "summed_variance", "std"):
                 getattr(graphed["norm"], f).copy_(getattr(normalizer_params, f))
         acc: Dict[str, torch.Tensor] = {}
