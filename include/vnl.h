@@ -213,6 +213,21 @@ typedef struct vnl_ppo_head_args {
 #define VNL_PPO_HEAD_WORKSPACE_FLOATS (4 + 4 * 256)
 int vnl_ppo_head(const vnl_ppo_head_args*, float* workspace, void* stream);
 
+/* ---- minibatch gather: dst_k[t][j][:] = src_k[t][idx[j]][:] for every array k of a time-major Transition
+ * (the index_select of brax's sgd_step, reference ppo_imitation/train.py:270-291), one launch for all arrays.
+ * src_k is [T_k][N][width_k], dst_k [T_k][M][width_k], 32-bit words; idx [M] int64 on the device. */
+typedef struct vnl_gather_op {
+  float* dst;
+  const float* src;
+  int32_t T, width;
+} vnl_gather_op;
+typedef struct vnl_gather_desc {
+  const int64_t* idx;
+  int32_t N, M, num_ops, pad_;
+  vnl_gather_op ops[VNL_POST_MAX_OPS];
+} vnl_gather_desc;
+int vnl_gather_rows(const vnl_gather_desc*, void* stream);
+
 /* ---- Adam on one flat buffer (optax.adam as the reference builds it, ppo_imitation/train.py:231-233:
  * b1 0.9, b2 0.999, eps 1e-8, no weight decay): mu, nu, params updated in place in ONE launch.
  * `count` is the device-resident step number AFTER this step (the caller increments it first), so that

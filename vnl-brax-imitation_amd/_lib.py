@@ -87,6 +87,15 @@ class PostDesc(C.Structure):  # include/vnl.h: vnl_post_desc
                 ("pad_", C.c_int32), ("ops", PostOp * POST_MAX_OPS)]
 
 
+class GatherOp(C.Structure):  # include/vnl.h: vnl_gather_op
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("T", C.c_int32), ("width", C.c_int32)]
+
+
+class GatherDesc(C.Structure):  # include/vnl.h: vnl_gather_desc
+    _fields_ = [("idx", C.c_void_p), ("N", C.c_int32), ("M", C.c_int32), ("num_ops", C.c_int32), ("pad_", C.c_int32),
+                ("ops", GatherOp * POST_MAX_OPS)]
+
+
 class PPOHeadArgs(C.Structure):  # include/vnl.h: vnl_ppo_head_args
     _fields_ = [(n, C.c_int32) for n in ("T", "B", "act", "latent")] + \
                [(n, C.c_void_p) for n in ("logits", "baseline", "bootstrap", "lat_mean", "lat_logvar", "raw_action",
@@ -103,7 +112,7 @@ PPO_HEAD_WORKSPACE_FLOATS = 4 + 4 * 256
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
     "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
-    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step",
+    "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step", "vnl_gather_rows",
 )
 
 
@@ -128,6 +137,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.vnl_rollout_post.argtypes = [C.POINTER(PostDesc), C.c_int32, vp]
     lib.vnl_ppo_head.argtypes = [C.POINTER(PPOHeadArgs), vp, vp]
+    lib.vnl_gather_rows.argtypes = [C.POINTER(GatherDesc), vp]
     lib.vnl_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int64] + [C.c_double] * 4 + [vp]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]

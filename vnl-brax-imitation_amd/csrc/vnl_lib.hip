@@ -836,6 +836,31 @@ extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* 
   return VNL_OK;
 }
 
+// ---- minibatch gather (include/vnl.h: vnl_gather_rows): one workgroup per selected row j, all arrays, all t
+__global__ void __launch_bounds__(VNL_POST_THREADS) vnl_gather_kernel(vnl_gather_desc d) {
+  const int j = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const long long src_row = d.idx[j];
+  for (int k = 0; k < d.num_ops; k++) {
+    const vnl_gather_op& op = d.ops[k];
+    const int w = op.width, total = op.T * w;
+    for (int i = tid; i < total; i += VNL_POST_THREADS) {
+      const int t = i / w, c = i - t * w;
+      ((unsigned*)op.dst)[((size_t)t * d.M + j) * w + c] = ((const unsigned*)op.src)[((size_t)t * d.N + src_row) * w + c];
+    }
+  }
+}
+
+extern "C" int vnl_gather_rows(const vnl_gather_desc* d, void* stream) {
+  if (!d || !d->idx || d->N <= 0 || d->M <= 0 || d->num_ops < 0 || d->num_ops > VNL_POST_MAX_OPS)
+    return fail(VNL_ERR_ARG, "vnl_gather_rows: bad descriptor");
+  for (int k = 0; k < d->num_ops; k++)
+    if (!d->ops[k].dst || !d->ops[k].src || d->ops[k].T <= 0 || d->ops[k].width <= 0)
+      return fail(VNL_ERR_ARG, "vnl_gather_rows: bad op");
+  hipLaunchKernelGGL(vnl_gather_kernel, dim3(d->M), dim3(VNL_POST_THREADS), 0, (hipStream_t)stream, *d);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
 // ---- Adam (include/vnl.h: vnl_adam_step) ----------------------------------------------------------
 #ifndef VNL_ADAM_THREADS
 #define VNL_ADAM_THREADS 256

@@ -235,13 +235,29 @@ def train(
         p = training_state.params
         saved = (p.detach().clone(), {k: v.clone() for k, v in training_state.optimizer_state.items()})
 
+        # the minibatch: static buffers filled by ONE vnl_gather_rows launch (brax's index_select per leaf)
+        import ctypes as C
+
+        from .. import _lib
+
+        full = g["full"]
+        src = acting.Transition(full.observation, full.action, full.reward, full.discount, full.next_observation[-1:],
+                                full.extras)  # only the bootstrap row of next_observation is read
+        g["mb"] = src.map(lambda x: torch.empty((x.shape[0], mb, *x.shape[2:]), dtype=x.dtype, device=device))
+        gd = _lib.GatherDesc()
+        gd.idx, gd.N, gd.M = C.c_void_p(g["idx"].data_ptr()), n, mb
+        pairs = list(zip(acting._leaves(g["mb"]), acting._leaves(src)))
+        assert len(pairs) <= _lib.POST_MAX_OPS
+        gd.num_ops = len(pairs)
+        for o, (dst, sr) in zip(gd.ops, pairs):
+            assert sr.is_contiguous() and sr.dtype in (torch.float32, torch.int32)
+            o.dst, o.src, o.T = C.c_void_p(dst.data_ptr()), C.c_void_p(sr.data_ptr()), sr.shape[0]
+            o.width = int(sr[0, 0].numel())
+        g["gather_desc"], lib = gd, base._L
+
         def body():
-            full, idx = g["full"], g["idx"]
-            mbd = acting.Transition(
-                full.observation.index_select(1, idx), full.action.index_select(1, idx),
-                full.reward.index_select(1, idx), full.discount.index_select(1, idx),
-                full.next_observation[-1:].index_select(1, idx),  # only the bootstrap row is read
-                {k: {kk: vv.index_select(1, idx) for kk, vv in v.items()} for k, v in full.extras.items()})
+            _lib.check(lib, lib.vnl_gather_rows(C.byref(gd), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+            mbd = g["mb"]
             leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
             loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"], time_major=True)
             loss.backward()
