@@ -75,8 +75,9 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
   do {                                                                         \
     dim3 g_ = (grid), b_ = (block);                                            \
     gridDim = g_, blockDim = b_;                                               \
-    for (unsigned bx_ = 0; bx_ < g_.x; bx_++) {                                \
-      blockIdx = dim3(bx_), threadIdx = dim3(0);                               \
-      kernel(__VA_ARGS__);                                                     \
-    }                                                                          \
+    for (unsigned by_ = 0; by_ < g_.y; by_++)                                  \
+      for (unsigned bx_ = 0; bx_ < g_.x; bx_++) {                              \
+        blockIdx = dim3(bx_, by_), threadIdx = dim3(0);                        \
+        kernel(__VA_ARGS__);                                                   \
+      }                                                                        \
   } while (0)

@@ -838,15 +838,15 @@ extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* 
 
 // ---- minibatch gather (include/vnl.h: vnl_gather_rows): one workgroup per selected row j, all arrays, all t
 __global__ void __launch_bounds__(VNL_POST_THREADS) vnl_gather_kernel(vnl_gather_desc d) {
-  const int j = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const int j = (int)blockIdx.x, t = (int)blockIdx.y, tid = (int)threadIdx.x;
   const long long src_row = d.idx[j];
   for (int k = 0; k < d.num_ops; k++) {
     const vnl_gather_op& op = d.ops[k];
-    const int w = op.width, total = op.T * w;
-    for (int i = tid; i < total; i += VNL_POST_THREADS) {
-      const int t = i / w, c = i - t * w;
-      ((unsigned*)op.dst)[((size_t)t * d.M + j) * w + c] = ((const unsigned*)op.src)[((size_t)t * d.N + src_row) * w + c];
-    }
+    if (t >= op.T) continue;
+    const int w = op.width;
+    const unsigned* src = (const unsigned*)op.src + ((size_t)t * d.N + src_row) * w;
+    unsigned* dst = (unsigned*)op.dst + ((size_t)t * d.M + j) * w;
+    for (int c = tid; c < w; c += VNL_POST_THREADS) dst[c] = src[c];
   }
 }
 
@@ -856,7 +856,9 @@ extern "C" int vnl_gather_rows(const vnl_gather_desc* d, void* stream) {
   for (int k = 0; k < d->num_ops; k++)
     if (!d->ops[k].dst || !d->ops[k].src || d->ops[k].T <= 0 || d->ops[k].width <= 0)
       return fail(VNL_ERR_ARG, "vnl_gather_rows: bad op");
-  hipLaunchKernelGGL(vnl_gather_kernel, dim3(d->M), dim3(VNL_POST_THREADS), 0, (hipStream_t)stream, *d);
+  int tmax = 1;
+  for (int k = 0; k < d->num_ops; k++) tmax = d->ops[k].T > tmax ? d->ops[k].T : tmax;
+  hipLaunchKernelGGL(vnl_gather_kernel, dim3(d->M, tmax), dim3(VNL_POST_THREADS), 0, (hipStream_t)stream, *d);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }
