@@ -1,0 +1,103 @@
+"""The kernels are model-generic: the reference's assets/ant.xml (14 dofs, 4 leaf chains, motor actuators, sphere
+feet) through the same source, against the dense oracle in float64.  Covers the code paths the rodent does not take
+(single lane set, the LDS factorisation fallback for models whose CG vectors are too small to hold the scratch
+lines).  BASELINE.json config 0 names this model; the reference's ant clip is not shipped, so the reference
+trajectory here is synthetic (forward kinematics of a smooth qpos sequence)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from vnl_brax_imitation_amd.model import mjcf
+from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as P
+
+ANT = "/root/reference/assets/ant.xml"
+ANT_COMPILED = os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "ant.npz")  # numeric constants of the compiled model
+
+
+def _ant_model():
+    return mjcf.CompiledModel.load(ANT_COMPILED)
+
+
+@pytest.mark.skipif(not os.path.exists(ANT), reason="reference checkout not present (GPU box)")
+def test_packaged_ant_model_is_the_compiled_reference_xml():
+    a, b = mjcf.compile_mjcf(ANT, scale_factor=1.0), _ant_model()
+    assert a.names == b.names and a.scalars.keys() == b.scalars.keys()
+    for k, v in a.arrays.items():
+        assert np.array_equal(np.asarray(v), np.asarray(b.arrays[k])), k
+
+
+def _ant_env(B, real, device="cpu"):
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+
+    m = _ant_model()
+    T = 40
+    t = np.arange(T)[:, None] * 0.02
+    qpos = np.zeros((T, 15))
+    qpos[:, 2], qpos[:, 3] = 0.55, 1.0
+    qpos[:, 0] = 0.2 * t[:, 0]
+    base = np.array([0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0])
+    qpos[:, 7:] = base + 0.15 * np.sin(2 * np.pi * 1.5 * t + np.arange(8))
+    clip = P.process_qpos(m, qpos, max_qvel=20.0, dt=0.02)
+    names = m.names
+    env = RodentTracking(
+        clip, end_eff_names=["aux_1", "aux_2", "aux_3", "aux_4"], appendage_names=["aux_1", "aux_2", "aux_3", "aux_4", "torso"],
+        walker_body_names=[n for n in names["body"] if n != "world"], joint_names=names["joint"][1:],
+        center_of_mass="torso", model=m, clip_length=T, sub_clip_length=10, ref_traj_length=5, healthy_z_range=(0.2, 1.0),
+        num_envs=B, device=device, _library=H.hostsim_library(real) if device == "cpu" else None,
+        _dtype=torch.float64 if real == "double" else torch.float32)
+    return env
+
+
+def test_ant_model_matches_dense_oracle_float64():
+    B = 8
+    env = _ant_env(B, "double")
+    d = env.dims
+    assert (d.nq, d.nv, d.nu, d.nbody) == (15, 14, 8, 14)
+    rng = np.random.default_rng(0)
+    sf = rng.integers(0, 30, B).astype(np.int32)
+    noise = 1e-3 * rng.standard_normal((B, 15))
+    st = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    o = H.make_oracle(env, "f64")
+    ost = o.env_reset(sf, noise)
+    ps = st.pipeline_state
+    for k in ("qpos", "qvel", "xpos", "qacc_warmstart"):
+        assert H.scaled_err(getattr(ps, k).reshape(B, -1).numpy(), ost[k]) < 1e-11, k
+    assert H.scaled_err(st.obs.numpy(), ost["obs"]) < 1e-11 and H.scaled_err(st.info["traj"].numpy(), ost["traj"]) < 1e-11
+    for _ in range(3):  # ground contact of the feet, joint limits, motor actuation
+        act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1)
+        st = env.step(st, torch.from_numpy(act))
+        o.env_step(ost, act)
+    assert H.scaled_err(ps.qpos.numpy(), ost["qpos"]) < 1e-7 and H.scaled_err(ps.qvel.numpy(), ost["qvel"]) < 1e-6
+    assert np.abs(st.reward.numpy() - ost["reward"]).max() < 1e-8
+    assert np.array_equal(st.done.numpy(), ost["done"]) and np.array_equal(st.info["cur_frame"].numpy(), ost["cur_frame"])
+    assert float(np.abs(ps.qvel.numpy()).max()) > 1e-2  # something moved
+
+
+@pytest.mark.gpu
+def test_ant_model_on_gpu_matches_oracle():
+    """The single-lane-set instantiations and the LDS factorisation fallback on the real device."""
+    B = 128
+    env = _ant_env(B, "float", device="cuda:0")
+    rng = np.random.default_rng(1)
+    sf = rng.integers(0, 30, B).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((B, 15))).astype(np.float32)
+    st = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    o = H.make_oracle(env, "f64")
+    ost = o.env_reset(sf, noise)
+    ps = st.pipeline_state
+    for k, tol in (("qpos", 1e-6), ("xpos", 2e-6), ("qacc_warmstart", 2e-5)):
+        assert H.scaled_err(getattr(ps, k).reshape(B, -1).cpu().numpy(), ost[k]) < tol, k
+    assert H.scaled_err(st.obs.cpu().numpy(), ost["obs"]) < 1e-6
+    for _ in range(2):
+        act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1).astype(np.float32)
+        st = env.step(st, torch.from_numpy(act))
+        o.env_step(ost, act)
+    per_env = np.array([H.scaled_err(ps.qvel[i].cpu().numpy(), ost["qvel"][i]) for i in range(B)])
+    assert np.median(per_env) < 1e-4 and np.quantile(per_env, 0.9) < 1e-2, (np.median(per_env), per_env.max())
+    # (one env in 128 sits on a contact switch: the float32 host build deviates there by the same 1e-2)
+    per_env_q = np.array([H.scaled_err(ps.qpos[i].cpu().numpy(), ost["qpos"][i]) for i in range(B)])
+    assert np.median(per_env_q) < 1e-5 and np.quantile(per_env_q, 0.9) < 1e-3, (np.median(per_env_q), per_env_q.max())
+    assert np.array_equal(st.done.cpu().numpy(), ost["done"].astype(np.float32))
