@@ -28,13 +28,17 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--updates", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank "
+                    "(exercises the data-parallel code path: eager all-reduce + Adam between graph replays)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29677")
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -58,7 +62,7 @@ def main():
         print(json.dumps({"env_steps": s, "training/sps": m["training/sps"], "wall_s": time.time() - t0,
                           "total_loss": m["training/total_loss"], "v_loss": m["training/v_loss"], "n_gpus": world,
                           "steps": args.steps, "updates_per_batch": args.updates}))
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 
