@@ -37,3 +37,26 @@ def test_graph_capture_matches_eager():
     for k in ("training/total_loss", "training/v_loss", "training/policy_loss", "training/kl_loss_intention"):
         assert abs(m0[k] - m1[k]) <= 1e-5 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
     assert torch.isfinite(f1).all()
+
+
+def test_training_with_evaluation_on_gpu():
+    """Full train() contract on the device: evaluator (EvalWrapper around the training wrappers, deterministic HIP
+    policy), progress / checkpoint callbacks, resumable state."""
+    dev = torch.device("cuda:0")
+    env = RodentTracking(H.reference_clip(), num_envs=64, device=dev, **H.env_kwargs())
+    eval_env = RodentTracking(H.reference_clip(), num_envs=32, device=dev, **H.env_kwargs())
+    nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=60,
+                           encoder_layer_sizes=(128, 128), decoder_layer_sizes=(128, 128))
+    log, saved = [], []
+    make_policy, params, metrics = ppo.train(
+        environment=env, num_timesteps=2 * 64 * 5, episode_length=20, num_envs=64, learning_rate=1e-3,
+        entropy_cost=1e-2, discounting=0.95, unroll_length=5, batch_size=16, num_minibatches=4,
+        num_updates_per_batch=2, num_evals=3, normalize_observations=True, network_factory=nf, num_eval_envs=32,
+        eval_env=eval_env, seed=1, progress_fn=lambda s, m: log.append((s, m)),
+        policy_params_fn=lambda s, mk, p: saved.append(s))
+    assert [s for s, _ in log] == [0, 320, 640] and saved == [320, 640]
+    for k in ("eval/episode_reward", "eval/avg_episode_length", "eval/sps", "training/sps", "training/total_loss"):
+        assert k in metrics and torch.isfinite(torch.tensor(float(metrics[k]))), k
+    assert 0 < metrics["eval/avg_episode_length"] <= 20
+    act, extras = make_policy(params, deterministic=True)(torch.zeros(4, 795, device=dev), torch.zeros(4, 232, device=dev), None)
+    assert act.shape == (4, 30) and extras == {} and torch.isfinite(act).all()
