@@ -64,6 +64,22 @@ VNL_HD float vnl_wave_sum(float x) {
          __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
 }
 VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row
+// totals are carried over with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+VNL_HD float vnl_wave_scan(float x) {
+#define VNL_DPP_SCAN(ctrl, rmask) \
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xf, false))
+  VNL_DPP_SCAN(0x111, 0xf);  // row_shr:1
+  VNL_DPP_SCAN(0x112, 0xf);  // row_shr:2
+  VNL_DPP_SCAN(0x114, 0xf);  // row_shr:4
+  VNL_DPP_SCAN(0x118, 0xf);  // row_shr:8
+  VNL_DPP_SCAN(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+  VNL_DPP_SCAN(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#undef VNL_DPP_SCAN
+  return x;
+}
+#define VNL_SCAN_ADD(x, run) (x = vnl_wave_scan(x)) /* x <- sum over items <= this one (run: host simulation only) */
+#define VNL_WAVE_ITEMS(n) VNL_LANES              /* trip count of a region in which every lane takes part in a scan */
 // one value per lane (item j of a <= 64-item region lives in lane j) + uniform-index broadcast
 #define VNL_PERLANE(T, name) T name
 #define VNL_AT(name, j) name
@@ -248,7 +264,7 @@ struct EnvWave {
       tb[2 * m.nbody + b] = (unsigned char)m.body_dofnum[b];
     }
     VNL_FOR(c, m.ncon) {
-      int cb = m.cg_body[m.con_geom[c]];
+      int cb = m.cg_body[m.con_geom[c] & 0xff];
       tb[3 * m.nbody + c] = (unsigned char)cb;
       tb[3 * m.nbody + m.ncon + c] = (unsigned char)m.body_lastdof[cb];
     }
@@ -629,15 +645,13 @@ struct EnvWave {
     // descendants; rows with disjoint subtrees share a step, each with its own scratch line
     // [row numerators (MAXD) | 1/pivot | j | pad], so the chain of dependent steps is the tree height.
     constexpr int LW = MAXD + 4;
-    int ftime[NSET], fslot[NSET];
-    vreal bb[NSET], myinv[NSET];  // SOLVE only
-    int leaf[NSET], lmask[NSET];
+    int ftime[NSET], fpack[NSET];  // fpack: scratch line | one leaf below << 8 | mask of all leaves below << 16
+    vreal bb[NSET], myinv[NSET];   // SOLVE only
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      const int pack = a < m.nv ? m.dof_fslot[a] : 0;
-      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1, fslot[q] = pack & 0xff;
-      leaf[q] = (pack >> 8) & 0xff, lmask[q] = pack >> 16;
+      fpack[q] = a < m.nv ? m.dof_fslot[a] : 0;
+      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1;
       bb[q] = (SOLVE && a < m.nv) ? s[rhs + a] : vreal(0.), myinv[q] = vreal(0.);
     }
     VNL_SYNC();
@@ -650,7 +664,7 @@ struct EnvWave {
         bool mine = ftime[q] == step;
         npub += VNL_COUNT(mine);
         if (mine) {
-          int line = sc + fslot[q] * LW, a = (int)lane + q * VNL_LANES;
+          int line = sc + (fpack[q] & 0xff) * LW, a = (int)lane + q * VNL_LANES;
 #pragma unroll
           for (int c0 = 0; c0 < MAXD; c0 += CH) {
             if (c0 < dep[q]) {
@@ -732,7 +746,7 @@ struct EnvWave {
     if constexpr (SOLVE) {
       VNL_SYNC();
       const int xs = sc;  // [leaf][MAXD] published x values; the scratch lines are no longer needed
-      vreal acc[NSET];
+      vreal(&acc)[NSET] = bb;  // (same registers: w is consumed here)
 #pragma unroll
       for (int q = 0; q < NSET; q++) acc[q] = bb[q] * myinv[q];  // D^-1 w
 #pragma unroll
@@ -743,13 +757,13 @@ struct EnvWave {
             int a = (int)lane + q * VNL_LANES;
             if (a < m.nv && dep[q] == c) {  // final: all ancestor terms are in
               s[rhs + a] = acc[q];
-              for (int mk = lmask[q]; mk != 0; mk &= mk - 1) s[xs + __builtin_ctz(mk) * MAXD + c] = acc[q];
+              for (int mk = fpack[q] >> 16; mk != 0; mk &= mk - 1) s[xs + __builtin_ctz(mk) * MAXD + c] = acc[q];
             }
           }
           VNL_WAVE_FENCE();
 #pragma unroll
           for (int q = 0; q < NSET; q++)
-            if (dep[q] > c) acc[q] -= rr[q][c] * myinv[q] * s[xs + leaf[q] * MAXD + c];
+            if (dep[q] > c) acc[q] -= rr[q][c] * myinv[q] * s[xs + ((fpack[q] >> 8) & 0xff) * MAXD + c];
         }
       }
       VNL_SYNC();
@@ -1138,7 +1152,7 @@ struct EnvWave {
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     VNL_FOR(j, na) {
-      int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
+      int c = act[j], g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
       int dl = con_lastdof(c);
       S6 vel = S6{v3(0, 0, 0), v3(0, 0, 0)};
       if (dl < m.nv) {
@@ -1184,44 +1198,57 @@ struct EnvWave {
   VNL_HD vreal constraint_force() const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     int Wc = L.P + 3 * m.nefc;  // after efc_D | Jaref | jv
-    const unsigned char* act = (const unsigned char*)(s + L.act_list);
-    int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     vreal cost = vreal(0.);
     VNL_FOR(r, m.nlimit) {
       vreal x = s[L.Jaref + r];
       cost += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
     }
-    VNL_FOR(j, na) {
-      int c = act[j], g = m.con_geom[c], r0 = m.nlimit + 4 * c;
-      vreal D = s[L.efc_D + r0];
-      vreal mu = m.cg_mu[g], f[4];
-      for (int q = 0; q < 4; q++) {
-        vreal x = s[L.Jaref + r0 + q];
-        f[q] = x < vreal(0.) ? -D * x : vreal(0.);
-        cost += x < vreal(0.) ? D * x * x : vreal(0.);
+    {
+      // Contacts are in body order and the subtree of a body is a contiguous body range, so the contacts under a
+      // dof are ONE range [c0, c1) (host table): one lane per contact forms its wrench (zero if inactive), a wave
+      // scan turns them into prefix sums P[k] = sum_{c<k}, and every dof takes P[c1] - P[c0] (exactly zero where
+      // nothing is active) -- no loop over contacts per dof.
+      S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)};
+      VNL_FOR(k, VNL_WAVE_ITEMS(m.ncon)) {  // (ncon <= 64: one trip of ALL lanes; idle lanes carry zeros through the scan)
+        S6 w = S6{v3(0, 0, 0), v3(0, 0, 0)};
+        if (k < m.ncon) {
+          const int c = (m.con_geom[k] >> 8) & 0xff;  // the k-th contact in body order
+          int r0 = m.nlimit + 4 * c;
+          vreal D = s[L.efc_D + r0];
+          if (D != vreal(0.)) {
+            int g = m.con_geom[c] & 0xff;
+            vreal mu = m.cg_mu[g], f[4];
+            for (int q = 0; q < 4; q++) {
+              vreal x = s[L.Jaref + r0 + q];
+              f[q] = x < vreal(0.) ? -D * x : vreal(0.);
+              cost += x < vreal(0.) ? D * x * x : vreal(0.);
+            }
+            V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
+            V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
+            w = S6{cross(rel, Fw), Fw};
+          }
+        }
+        VNL_SCAN_ADD(w.a.x, run.a.x), VNL_SCAN_ADD(w.a.y, run.a.y), VNL_SCAN_ADD(w.a.z, run.a.z);
+        VNL_SCAN_ADD(w.l.x, run.l.x), VNL_SCAN_ADD(w.l.y, run.l.y), VNL_SCAN_ADD(w.l.z, run.l.z);
+        if (k < m.ncon) st6(Wc + 6 * (k + 1), w);
+        if (k == 0) st6(Wc, S6{v3(0, 0, 0), v3(0, 0, 0)});
       }
-      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
-      V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
-      st6(Wc + 6 * j, S6{cross(rel, Fw), Fw});
+      VNL_SYNC();
+      VNL_FOR(d, m.nv) {
+        const int pk = m.dof_limrow[d], r = (pk & 0x3ff) - 1, c0 = (pk >> 10) & 0xff, c1 = (pk >> 18) & 0xff;
+        S6 p1 = ld6(Wc + 6 * c1), p0 = ld6(Wc + 6 * c0);
+        S6 w = S6{p1.a - p0.a, p1.l - p0.l};
+        vreal q = dot(ld6(L.cdof + 6 * d), w);
+        if (r >= 0) {
+          vreal x = s[L.Jaref + r];
+          q += x < vreal(0.) ? -s[L.efc_D + r] * x : vreal(0.);  // sign(D) is the limit Jacobian entry
+        }
+        s[L.qfrc_c + d] = q;
+      }
+      VNL_SYNC();
+      return vreal(0.5) * vnl_wave_sum(cost);
     }
-    VNL_SYNC();
-    VNL_FOR(d, m.nv) {
-      int b0 = m.dof_body[d], b1 = b0 + m.body_nsub[b0];
-      S6 w = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      for (int j = 0; j < na; j++) {
-        int cb = con_body(act[j]);
-        if (cb >= b0 && cb <= b1) w = w + ld6(Wc + 6 * j);
-      }
-      vreal q = dot(ld6(L.cdof + 6 * d), w);
-      int r = m.dof_limrow[d];
-      if (r >= 0) {
-        vreal x = s[L.Jaref + r];
-        q += x < vreal(0.) ? -s[L.efc_D + r] * x : vreal(0.);  // sign(D) is the limit Jacobian entry
-      }
-      s[L.qfrc_c + d] = q;
-    }
-    VNL_SYNC();
-    return vreal(0.5) * vnl_wave_sum(cost);
+    return vreal(0.);  // (build_dev_model rejects models whose contacts do not fit one wave)
   }
 
   VNL_HD vreal vdot(int a, int b) const {

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -141,6 +142,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   if (const char* dbg = getenv("VNL_DBG_REPEAT")) sscanf(dbg, "%d:%d", &d.dbg_stage, &d.dbg_count);
   d.scale = (vreal)(S("meaninertia") * (d.nv > 1 ? d.nv : 1));
   const int nb = d.nbody, nj = d.njnt, nv = d.nv, nu = d.nu, ng = d.ncg;
+  std::vector<int> nsub_host, limrow_host;  // kept for the per-dof contact ranges further down
   struct Need {
     const char* k;
     size_t n;
@@ -217,6 +219,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         if (!in) return fail(VNL_ERR_UNSUPPORTED, "body numbering is not depth-first");
       }
     UPI(body_nsub, nsub)
+    nsub_host = nsub;
     std::vector<int> lastdof(nb, nv);  // last dof on the path from the root to (and including) body b; nv = none
     for (int b = 1; b < nb; b++) lastdof[b] = dn[b] > 0 ? da[b] + dn[b] - 1 : lastdof[bp[b]];
     UPI(body_lastdof, lastdof)
@@ -322,7 +325,8 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         if (I("jnt_limited")[j] && jt[j] == VNL_JNT_HINGE) limrow[I("jnt_dofadr")[j]] = r++;
     }
     UPI(dof_body, I("dof_bodyid")) UPI(dof_Madr, madr) UPI(dof_depth, depth) UPI(M_anc, anc) UPI(M_row, row)
-    UPI(dof_ndesc, ndesc) UPI(dof_limrow, limrow)
+    UPI(dof_ndesc, ndesc)
+    limrow_host = limrow;
     // Factorisation schedule: row j can be the pivot once all its descendants have been; rows whose
     // subtrees are disjoint go in the same step (at most VNL_FAC_LINES of them, one scratch line each).
     std::vector<int> ftime(nv, 0), fslot(nv, 0), count;
@@ -370,7 +374,28 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     std::vector<int> cgeom(d.ncon, 0);
     for (int g = 0; g < ng; g++)
       for (int q = 0; q < I("cg_ncon")[g]; q++) cgeom[I("cg_conadr")[g] + q] = g;
+    // The contacts under a dof (subtree of its body = contiguous body range) form ONE range [c0, c1) of the
+    // contacts SORTED BY BODY: con_geom[k] carries the geom of contact k in its low byte and, in the next byte, the
+    // k-th contact in body order; the range is packed next to the dof's limit row as
+    // (limrow + 1) | c0 << 10 | c1 << 18 | valid << 26 (constraint_force sums wrenches by prefix differences).
+    const auto& cgb = I("cg_bodyid");
+    const bool ok_ = d.ncon <= 64 && d.nlimit < 1023 && ng < 256;
+    if (!ok_) return fail(VNL_ERR_UNSUPPORTED, "more than 64 contacts / 255 collision geoms / 1022 limit rows (constraint_force scans the contact wrenches in one wave)");
+    std::vector<int> order(d.ncon);
+    for (int c = 0; c < d.ncon; c++) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cgb[cgeom[a]] < cgb[cgeom[b]]; });
+    if (ok_)
+      for (int k = 0; k < d.ncon; k++) cgeom[k] |= order[k] << 8;
     UPI(con_geom, cgeom)
+    std::vector<int> packed(nv);
+    for (int dd = 0; dd < nv; dd++) {
+      int b0 = I("dof_bodyid")[dd], b1 = b0 + nsub_host[b0], c0 = 0, c1 = 0;
+      while (c0 < d.ncon && cgb[cgeom[order[c0]] & 0xff] < b0) c0++;
+      c1 = c0;
+      while (c1 < d.ncon && cgb[cgeom[order[c1]] & 0xff] <= b1) c1++;
+      packed[dd] = (limrow_host[dd] + 1) | (c0 << 10) | (c1 << 18) | ((ok_ ? 1 : 0) << 26);
+    }
+    UPI(dof_limrow, packed)
   }
   UPF(cg_pos, F("cg_pos")) UPF(cg_quat, F("cg_quat")) UPF(cg_size, F("cg_size")) UPF(cg_solref, F("cg_solref"))
   UPF(cg_solimp, F("cg_solimp")) UPF(cg_margin, F("cg_margin"))
