@@ -624,10 +624,13 @@ struct EnvWave {
   // never stored, and x = L^-1 D^-1 w follows by a forward substitution over the depth: the rows of depth c
   // publish their x once per leaf below them, every deeper row reads "its" ancestor's x at a static offset.
   // Replaces factor + inversion + two sparse products for that system.
-  template <int NSET, int MAXD, bool SOLVE = false>
+  // MAXD1: column bound of the SECOND lane set (rows 64 .. 127) when there are exactly two: those rows are often
+  // shallow (rodent: depth <= 13), and registers for columns they do not have would be dead weight.
+  template <int NSET, int MAXD, bool SOLVE = false, int MAXD1 = MAXD>
   VNL_HD void factor_rows(bool with_loop = true, int rhs = 0) const {
     static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
     constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
+    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
     vreal rr[NSET][MAXD], dg[NSET];
     int dep[NSET], last[NSET];
     const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; VNL_FAC_LINES * (MAXD + 4) floats
@@ -639,7 +642,8 @@ struct EnvWave {
       dep[q] = d, last[q] = ok ? a + m.dof_ndesc[a] : -1;
       dg[q] = ok ? s[L.LD + adr] : vreal(1.);
 #pragma unroll
-      for (int c = 0; c < MAXD; c++) rr[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
+      for (int c = 0; c < MAXD; c++)
+        if (c < qd(q)) rr[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
     }
     // Schedule (host, build_dev_model): row j is the pivot of step dof_ftime[j], after all of its
     // descendants; rows with disjoint subtrees share a step, each with its own scratch line
@@ -667,9 +671,10 @@ struct EnvWave {
           int line = sc + (fpack[q] & 0xff) * LW, a = (int)lane + q * VNL_LANES;
 #pragma unroll
           for (int c0 = 0; c0 < MAXD; c0 += CH) {
-            if (c0 < dep[q]) {
+            if (c0 < qd(q) && c0 < dep[q]) {
 #pragma unroll
-              for (int c = c0; c < c0 + CH; c += 4) st4a(s + line + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
+              for (int c = c0; c < c0 + CH; c += 4)
+                if (c < qd(q)) st4a(s + line + c, rr[q][c], rr[q][c + 1], rr[q][c + 2], rr[q][c + 3]);
             }
           }
           vreal inv = vnl_recip(dg[q]);
@@ -728,11 +733,13 @@ struct EnvWave {
             }
 #pragma unroll
             for (int c0 = CH; c0 < MAXD; c0 += CH) {
-              if (c0 < dep[q]) {
+              if (c0 < qd(q) && c0 < dep[q]) {
 #pragma unroll
                 for (int c = c0; c < c0 + CH; c += 4) {
-                  R4 x = ld4a(line + c);
-                  rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+                  if (c < qd(q)) {
+                    R4 x = ld4a(line + c);
+                    rr[q][c] -= t * x.x, rr[q][c + 1] -= t * x.y, rr[q][c + 2] -= t * x.z, rr[q][c + 3] -= t * x.w;
+                  }
                 }
               }
             }
@@ -763,7 +770,7 @@ struct EnvWave {
           VNL_WAVE_FENCE();
 #pragma unroll
           for (int q = 0; q < NSET; q++)
-            if (dep[q] > c) acc[q] -= rr[q][c] * myinv[q] * s[xs + ((fpack[q] >> 8) & 0xff) * MAXD + c];
+            if (c < qd(q) && dep[q] > c) acc[q] -= rr[q][c] * myinv[q] * s[xs + ((fpack[q] >> 8) & 0xff) * MAXD + c];
         }
       }
       VNL_SYNC();
@@ -780,7 +787,7 @@ struct EnvWave {
         s[L.LD + adr] = dg[q];
 #pragma unroll
         for (int c = 0; c < MAXD; c++)
-          if (c < d) s[L.LD + adr + d - c] = rr[q][c] * di;
+          if (c < qd(q) && c < d) s[L.LD + adr + d - c] = rr[q][c] * di;
       }
     }
     VNL_SYNC();
@@ -790,8 +797,9 @@ struct EnvWave {
   // L -> L^-1 in place from N L = I:  N(i,t) = -L(i,t) - sum_{0<u<t} N(i,u) L(anc_u(i), t-u).  Row i of
   // N only needs its own earlier entries (registers) and the ORIGINAL rows of its ancestors, so all
   // rows run at once without levels; the results are written back after one barrier.
-  template <int NSET, int MAXD>
+  template <int NSET, int MAXD, int MAXD1 = MAXD>
   VNL_HD void invert_rows() const {
+    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
     // Sets are taken from the last to the first and written back one at a time: rows of a later
     // set are never ancestors of rows of an earlier one.
 #pragma unroll
@@ -803,10 +811,11 @@ struct EnvWave {
       int own = L.LD + adr;
       const vreal* pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
 #pragma unroll
-      for (int u = 1; u < MAXD; u++) pb[u] = s + L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
+      for (int u = 1; u < MAXD; u++)
+        if (u < qd(q)) pb[u] = s + L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
 #pragma unroll
       for (int t = 1; t < MAXD; t++) {
-        if (vnl_wave_any(t <= d)) {
+        if (t < qd(q) && vnl_wave_any(t <= d)) {
           vreal x[MAXD];  // all operands of entry t are fetched before the (dependent) multiply-add chain
 #pragma unroll
           for (int u = 1; u < t; u++) x[u] = pb[u][t - u];
@@ -819,7 +828,7 @@ struct EnvWave {
       VNL_SYNC();
 #pragma unroll
       for (int t = 1; t < MAXD; t++)
-        if (t <= d) s[own + t] = nn[t];
+        if (t < qd(q) && t <= d) s[own + t] = nn[t];
       VNL_SYNC();
     }
   }
@@ -830,7 +839,9 @@ struct EnvWave {
     const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16>(with_loop);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36>(with_loop);
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_2, 36>(with_loop);
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (m.fac_nleaf >> 8) < 16)
+      factor_rows<VNL_ROWSETS_2, 36, false, 16>(with_loop);  // (a second lane set with deeper rows takes the LDS route:
+                                                             // every instantiation costs registers for the whole kernel)
     else factor_lds();
   }
   // solve (matrix in LD) x = s[rhs .. rhs+nv) in place without storing a factor; false if this model needs the
@@ -838,10 +849,11 @@ struct EnvWave {
   VNL_HD bool factor_solve(int rhs) const {
     const int nv = m.nv, md = m.max_depth;
     const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
-    if (m.fac_nleaf == 0) return false;
+    if ((m.fac_nleaf & 0xff) == 0) return false;
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16, true>(true, rhs);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36, true>(true, rhs);
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_2, 36, true>(true, rhs);
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (m.fac_nleaf >> 8) < 16)
+      factor_rows<VNL_ROWSETS_2, 36, true, 16>(true, rhs);
     else return false;
     return true;
   }
@@ -849,7 +861,7 @@ struct EnvWave {
     const int nv = m.nv, md = m.max_depth;
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_rows<VNL_ROWSETS_1, 16>();
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_1, 36>();
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_2, 36>();
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16) invert_rows<VNL_ROWSETS_2, 36, 16>();
     else invert_factor_lds();
   }
 

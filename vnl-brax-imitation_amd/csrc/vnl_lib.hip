@@ -351,6 +351,8 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       for (int j = 0; j < nv; j++)
         if (ndesc[j] == 0) leaf_id[j] = nleaf++;
       d.fac_nleaf = nleaf <= VNL_FAC_LINES ? nleaf : 0;
+      int deep1 = 0;  // deepest row of the second lane set (rows 64 ..): bits 8.. of fac_nleaf
+      for (int j = 64; j < nv; j++) deep1 = depth[j] > deep1 ? depth[j] : deep1;
       if (d.fac_nleaf)
         for (int a = 0; a < nv; a++) {
           int mask = 0;
@@ -358,6 +360,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
             if (leaf_id[j] >= 0) mask |= 1 << leaf_id[j];
           fslot[a] |= (leaf_id[a + ndesc[a]] << 8) | (mask << 16);  // the last descendant is a leaf
         }
+      d.fac_nleaf |= deep1 << 8;
     }
     UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
   }

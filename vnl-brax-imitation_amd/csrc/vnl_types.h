@@ -22,7 +22,8 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
   int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
   int fac_steps; /* number of steps of the factorisation schedule */
-  int fac_nleaf; /* leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand side), else 0 */
+  int fac_nleaf; /* low byte: leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand
+                    side), else 0; bits 8..: depth of the deepest of the rows 64 .. (second lane set) */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
