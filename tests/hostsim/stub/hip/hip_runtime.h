@@ -61,6 +61,8 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define vnl_wave_any(x) (x)
 #define VNL_SCAN_ADD(x, run) (run += (x), x = run)
 #define VNL_WAVE_ITEMS(n) (n)
+#define VNL_PAD_ITEMS(n) (n)
+#define VNL_SCAN_ADD_C(x, run, carry) (run += (x), x = run)
 #define VNL_PERLANE(T, name) T name[64]
 #define VNL_AT(name, j) name[j]
 #define VNL_GETF(name, a) name[a]

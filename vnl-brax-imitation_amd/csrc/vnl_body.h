@@ -80,6 +80,10 @@ VNL_HD float vnl_wave_scan(float x) {
 }
 #define VNL_SCAN_ADD(x, run) (x = vnl_wave_scan(x)) /* x <- sum over items <= this one (run: host simulation only) */
 #define VNL_WAVE_ITEMS(n) VNL_LANES              /* trip count of a region in which every lane takes part in a scan */
+#define VNL_PAD_ITEMS(n) (((n) + VNL_LANES - 1) / VNL_LANES * VNL_LANES) /* .. over several trips */
+// scan carried across trips: x <- sum over all items up to this one; carry = total so far (the last lane's value)
+#define VNL_SCAN_ADD_C(x, run, carry) \
+  (x = vnl_wave_scan(x) + carry, carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63)))
 // one value per lane (item j of a <= 64-item region lives in lane j) + uniform-index broadcast
 #define VNL_PERLANE(T, name) T name
 #define VNL_AT(name, j) name
@@ -1152,34 +1156,41 @@ struct EnvWave {
     VNL_SYNC();
   }
 
-  // out[r] = (J vec)[r]  (accumulate: out[r] += ...).  Limit rows: one lane each.  Contact rows: one
-  // lane per ACTIVE contact; the twist of the contact's body is summed along that body's own dof
-  // path (ancestor list of its last dof), so no tree pass and no synchronisation is needed.
+  // out[r] = (J vec)[r]  (accumulate: out[r] += ...).  Limit rows: one lane each.  Contact rows: the twist of
+  // a contact's body is the sum of cdof_d * vec_d over the dofs d on the body's path; those dofs are a few runs of
+  // consecutive indices (host table body_pathseg), so ONE prefix-sum array Q[k] = sum_{d<k} cdof_d vec_d (a wave
+  // scan, carried across the trips) serves every contact: twist = sum over runs of Q[end] - Q[begin].
   VNL_HD void jac_mul(int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     VNL_FOR(r, m.nlimit) {
       vreal v = copysign(vreal(1.), s[L.efc_D + r]) * s[vec + m.lim_dof[r]];
       s[out + r] = accumulate ? s[out + r] + v : v;
     }
+    const int Q = L.P + 3 * m.nefc;  // the contact-wrench area of constraint_force: dead here
+    {
+      S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
+      VNL_FOR(d, VNL_PAD_ITEMS(m.nv)) {  // every lane takes part in the scans of every trip
+        S6 x = S6{v3(0, 0, 0), v3(0, 0, 0)};
+        if (d < m.nv) x = ld6(L.cdof + 6 * d) * s[vec + d];
+        VNL_SCAN_ADD_C(x.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(x.a.y, run.a.y, carry.a.y);
+        VNL_SCAN_ADD_C(x.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(x.l.x, run.l.x, carry.l.x);
+        VNL_SCAN_ADD_C(x.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(x.l.z, run.l.z, carry.l.z);
+        if (d < m.nv) st6(Q + 6 * (d + 1), x);
+        if (d == 0) st6(Q, S6{v3(0, 0, 0), v3(0, 0, 0)});
+      }
+    }
+    VNL_SYNC();
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     VNL_FOR(j, na) {
       int c = act[j], g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
-      int dl = con_lastdof(c);
+      const int* seg = m.body_pathseg + 4 * con_body(c);
       S6 vel = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      if (dl < m.nv) {
-        int adr = madr(dl), dep = eadr(dl) - adr;
-        const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
-        int t = 0;
-        for (; t + 1 <= dep; t += 2) {  // two independent (index -> cdof, vec) chains per trip
-          int d0 = an[t], d1 = an[t + 1];
-          vreal w0 = s[vec + d0], w1 = s[vec + d1];
-          vel = vel + ld6(L.cdof + 6 * d0) * w0 + ld6(L.cdof + 6 * d1) * w1;
-        }
-        for (; t <= dep; t++) {
-          int d0 = an[t];
-          vel = vel + ld6(L.cdof + 6 * d0) * s[vec + d0];
-        }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int sg = seg[k], b = sg & 0xff, e = sg >> 8;  // (an unused run is 0 | 0 << 8: Q[0] - Q[0])
+        S6 qe = ld6(Q + 6 * e), qb = ld6(Q + 6 * b);
+        vel = S6{vel.a + (qe.a - qb.a), vel.l + (qe.l - qb.l)};
       }
       vreal mu = m.cg_mu[g];
       V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);

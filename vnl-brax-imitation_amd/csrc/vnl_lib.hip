@@ -223,6 +223,26 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     std::vector<int> lastdof(nb, nv);  // last dof on the path from the root to (and including) body b; nv = none
     for (int b = 1; b < nb; b++) lastdof[b] = dn[b] > 0 ? da[b] + dn[b] - 1 : lastdof[bp[b]];
     UPI(body_lastdof, lastdof)
+    // The dofs on the path root -> body b as (at most 4) runs of consecutive dof indices, begin | end << 8 each:
+    // jac_mul sums a body twist as differences of ONE prefix-sum array over the dofs instead of walking the path.
+    {
+      const auto& dpar = I("dof_parentid");
+      std::vector<int> seg(4 * (size_t)nb, 0);
+      for (int b = 1; b < nb; b++) {
+        std::vector<int> path;
+        for (int dd = lastdof[b] < nv ? lastdof[b] : -1; dd >= 0; dd = dpar[dd]) path.push_back(dd);
+        std::sort(path.begin(), path.end());
+        int nseg = 0;
+        for (size_t i = 0; i < path.size();) {
+          size_t j = i;
+          while (j + 1 < path.size() && path[j + 1] == path[j] + 1) j++;
+          if (nseg == 4) return fail(VNL_ERR_UNSUPPORTED, "a body path has more than 4 runs of consecutive dofs");
+          seg[4 * b + nseg++] = path[i] | ((path[j] + 1) << 8);
+          i = j + 1;
+        }
+      }
+      UPI(body_pathseg, seg)
+    }
     int bdepth = 0;
     for (int b = 1; b < nb; b++) {
       int dd = 0;
@@ -433,7 +453,8 @@ static void layout(vnl_env* env) {
   L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
   L.actdot = sec("act_dot", d.nu), L.com = sec("subtree_com1", 4);
   L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
-  int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + 6 * d.ncon);
+  // solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul
+  int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
   L.P = sec("pool", pool);
   L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
   env->sections["efc_D"] = {L.efc_D, d.nefc}, env->sections["Jaref"] = {L.Jaref, d.nefc};
