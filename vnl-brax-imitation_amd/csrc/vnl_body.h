@@ -948,16 +948,12 @@ struct EnvWave {
   VNL_HD int bias_forces() const {
     int nb6 = 6 * m.nbody;
     int X0 = L.P + 10 * m.nbody, X1 = X0 + nb6;  // after cinert; cvel has to end in X1 (X0 is reused)
-    int start = (m.jump_rounds & 1) ? X0 : X1;
-    VNL_FOR(i, nb6) {
-      int b = i / 6, k = i - 6 * b;
-      int da = dofadr_of(b), nd = dofnum_of(b);
-      vreal v = vreal(0.);
-      for (int t = 0; t < nd; t++) v += s[L.cdof + 6 * (da + t) + k] * s[L.qvel + da + t];
-      s[start + i] = v;
-    }
+    // cvel[b] = sum of cdof_d qvel_d over the dofs on b's path: differences of the dof prefix sums (parked in the
+    // factor buffer, which is free until the mass matrix is built)
+    dof_prefix(L.qvel, L.LD);
+    const int cv = X1;
+    VNL_FOR(b, m.nbody) st6(cv + 6 * b, path_sum(L.LD, m.body_pathseg + 4 * b));
     VNL_SYNC();
-    int cv = tree_prefix(start, start == X0 ? X1 : X0);  // == X1
     VNL_PROF(2);
     int ca = X0;
     VNL_FOR(b, m.nbody) {  // own acceleration term: sum over the body's dofs of cdof_dot * qvel
@@ -1156,6 +1152,32 @@ struct EnvWave {
     VNL_SYNC();
   }
 
+  // Q[k] = sum_{d<k} cdof_d * vec_d, k = 0 .. nv (6 floats each): a wave scan carried across the trips
+  VNL_HD void dof_prefix(int vec, int Q) const {
+    S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
+    VNL_FOR(d, VNL_PAD_ITEMS(m.nv)) {  // every lane takes part in the scans of every trip
+      S6 x = S6{v3(0, 0, 0), v3(0, 0, 0)};
+      if (d < m.nv) x = ld6(L.cdof + 6 * d) * s[vec + d];
+      VNL_SCAN_ADD_C(x.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(x.a.y, run.a.y, carry.a.y);
+      VNL_SCAN_ADD_C(x.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(x.l.x, run.l.x, carry.l.x);
+      VNL_SCAN_ADD_C(x.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(x.l.z, run.l.z, carry.l.z);
+      if (d < m.nv) st6(Q + 6 * (d + 1), x);
+      if (d == 0) st6(Q, S6{v3(0, 0, 0), v3(0, 0, 0)});
+    }
+    VNL_SYNC();
+  }
+  // sum over the (at most 4) runs of consecutive dofs on a body's path: Q[end] - Q[begin] each
+  VNL_HD S6 path_sum(int Q, const int* seg) const {
+    S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int sg = seg[k], b = sg & 0xff, e = sg >> 8;  // (an unused run is 0 | 0 << 8: Q[0] - Q[0])
+      S6 qe = ld6(Q + 6 * e), qb = ld6(Q + 6 * b);
+      acc = S6{acc.a + (qe.a - qb.a), acc.l + (qe.l - qb.l)};
+    }
+    return acc;
+  }
+
   // out[r] = (J vec)[r]  (accumulate: out[r] += ...).  Limit rows: one lane each.  Contact rows: the twist of
   // a contact's body is the sum of cdof_d * vec_d over the dofs d on the body's path; those dofs are a few runs of
   // consecutive indices (host table body_pathseg), so ONE prefix-sum array Q[k] = sum_{d<k} cdof_d vec_d (a wave
@@ -1167,31 +1189,13 @@ struct EnvWave {
       s[out + r] = accumulate ? s[out + r] + v : v;
     }
     const int Q = L.P + 3 * m.nefc;  // the contact-wrench area of constraint_force: dead here
-    {
-      S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
-      VNL_FOR(d, VNL_PAD_ITEMS(m.nv)) {  // every lane takes part in the scans of every trip
-        S6 x = S6{v3(0, 0, 0), v3(0, 0, 0)};
-        if (d < m.nv) x = ld6(L.cdof + 6 * d) * s[vec + d];
-        VNL_SCAN_ADD_C(x.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(x.a.y, run.a.y, carry.a.y);
-        VNL_SCAN_ADD_C(x.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(x.l.x, run.l.x, carry.l.x);
-        VNL_SCAN_ADD_C(x.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(x.l.z, run.l.z, carry.l.z);
-        if (d < m.nv) st6(Q + 6 * (d + 1), x);
-        if (d == 0) st6(Q, S6{v3(0, 0, 0), v3(0, 0, 0)});
-      }
-    }
-    VNL_SYNC();
+    dof_prefix(vec, Q);
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     VNL_FOR(j, na) {
       int c = act[j], g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
       const int* seg = m.body_pathseg + 4 * con_body(c);
-      S6 vel = S6{v3(0, 0, 0), v3(0, 0, 0)};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int sg = seg[k], b = sg & 0xff, e = sg >> 8;  // (an unused run is 0 | 0 << 8: Q[0] - Q[0])
-        S6 qe = ld6(Q + 6 * e), qb = ld6(Q + 6 * b);
-        vel = S6{vel.a + (qe.a - qb.a), vel.l + (qe.l - qb.l)};
-      }
+      S6 vel = path_sum(Q, seg);
       vreal mu = m.cg_mu[g];
       V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
       V3 pv = vel.l + cross(vel.a, rel);

@@ -452,7 +452,7 @@ static void layout(vnl_env* env) {
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
   L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
   L.actdot = sec("act_dot", d.nu), L.com = sec("subtree_com1", 4);
-  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", d.nM), L.dinv = sec("qLDiagInv", d.nv);
+  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", imax(d.nM, 6 * (d.nv + 1)))  /* also holds the dof prefix sums of bias_forces */, L.dinv = sec("qLDiagInv", d.nv);
   // solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul
   int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
   L.P = sec("pool", pool);
