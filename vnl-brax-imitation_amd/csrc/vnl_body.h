@@ -952,13 +952,17 @@ struct EnvWave {
     // factor buffer, which is free until the mass matrix is built)
     dof_prefix(L.qvel, L.LD);
     const int cv = X1;
-    VNL_FOR(b, m.nbody) st6(cv + 6 * b, path_sum(L.LD, m.body_pathseg + 4 * b));
+    VNL_FOR(b, m.nbody) st6(cv + 6 * b, path_sum(L.LD, m.body_pathseg + 8 * b));
     VNL_SYNC();
     VNL_PROF(2);
     int ca = X0;
-    VNL_FOR(b, m.nbody) {  // own acceleration term: sum over the body's dofs of cdof_dot * qvel
+    // own acceleration term of every body (sum over its dofs of cdof_dot * qvel), prefix-summed over the body index
+    // in the same pass; cacc[b] = sum over b's ancestors = differences over its runs of consecutive ancestor bodies
+    const int QB = L.LD + 6 * (m.nv + 1);
+    S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
+    VNL_FOR(b, VNL_PAD_ITEMS(m.nbody)) {
       S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      if (b > 0) {
+      if (b > 0 && b < m.nbody) {
         S6 vel = ld6(cv + 6 * parent_of(b));
         int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
         for (int k = 0; k < jn; k++) {
@@ -980,10 +984,15 @@ struct EnvWave {
           }
         }
       }
-      st6(ca + 6 * b, acc);
+      VNL_SCAN_ADD_C(acc.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(acc.a.y, run.a.y, carry.a.y);
+      VNL_SCAN_ADD_C(acc.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(acc.l.x, run.l.x, carry.l.x);
+      VNL_SCAN_ADD_C(acc.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(acc.l.z, run.l.z, carry.l.z);
+      if (b < m.nbody) st6(QB + 6 * (b + 1), acc);
+      if (b == 0) st6(QB, S6{v3(0, 0, 0), v3(0, 0, 0)});
     }
     VNL_SYNC();
-    tree_prefix_inplace(ca);
+    VNL_FOR(b, m.nbody) st6(ca + 6 * b, path_sum(QB, m.body_pathseg + 8 * b + 4));
+    VNL_SYNC();
     VNL_PROF(3);
     VNL_FOR(b, m.nbody) {  // cfrc overwrites cacc in place (each body only needs its own entries)
       if (b == 0) {
@@ -1194,7 +1203,7 @@ struct EnvWave {
     int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
     VNL_FOR(j, na) {
       int c = act[j], g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
-      const int* seg = m.body_pathseg + 4 * con_body(c);
+      const int* seg = m.body_pathseg + 8 * con_body(c);
       S6 vel = path_sum(Q, seg);
       vreal mu = m.cg_mu[g];
       V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);

@@ -227,8 +227,21 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     // jac_mul sums a body twist as differences of ONE prefix-sum array over the dofs instead of walking the path.
     {
       const auto& dpar = I("dof_parentid");
-      std::vector<int> seg(4 * (size_t)nb, 0);
+      std::vector<int> seg(8 * (size_t)nb, 0);  // per body: 4 runs of dofs, then 4 runs of ancestor bodies (incl. itself)
       for (int b = 1; b < nb; b++) {
+        {
+          std::vector<int> anc;
+          for (int a = b; a > 0; a = bp[a]) anc.push_back(a);
+          std::sort(anc.begin(), anc.end());
+          int nseg = 0;
+          for (size_t i = 0; i < anc.size();) {
+            size_t j = i;
+            while (j + 1 < anc.size() && anc[j + 1] == anc[j] + 1) j++;
+            if (nseg == 4) return fail(VNL_ERR_UNSUPPORTED, "a body has more than 4 runs of consecutive ancestor bodies");
+            seg[8 * b + 4 + nseg++] = anc[i] | ((anc[j] + 1) << 8);
+            i = j + 1;
+          }
+        }
         std::vector<int> path;
         for (int dd = lastdof[b] < nv ? lastdof[b] : -1; dd >= 0; dd = dpar[dd]) path.push_back(dd);
         std::sort(path.begin(), path.end());
@@ -237,7 +250,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
           size_t j = i;
           while (j + 1 < path.size() && path[j + 1] == path[j] + 1) j++;
           if (nseg == 4) return fail(VNL_ERR_UNSUPPORTED, "a body path has more than 4 runs of consecutive dofs");
-          seg[4 * b + nseg++] = path[i] | ((path[j] + 1) << 8);
+          seg[8 * b + nseg++] = path[i] | ((path[j] + 1) << 8);
           i = j + 1;
         }
       }
@@ -452,7 +465,7 @@ static void layout(vnl_env* env) {
   auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
   L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
   L.actdot = sec("act_dot", d.nu), L.com = sec("subtree_com1", 4);
-  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", imax(d.nM, 6 * (d.nv + 1)))  /* also holds the dof prefix sums of bias_forces */, L.dinv = sec("qLDiagInv", d.nv);
+  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", imax(d.nM, 6 * (d.nv + 1) + 6 * (d.nbody + 1)))  /* also holds the dof / body prefix sums of bias_forces */, L.dinv = sec("qLDiagInv", d.nv);
   // solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul
   int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
   L.P = sec("pool", pool);

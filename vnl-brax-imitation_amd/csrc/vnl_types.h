@@ -33,7 +33,8 @@ struct DevModel {
   vreal root_px, root_py, root_pz; /* reference point when the root is not a free joint */
   // bodies
   const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub, *body_lastdof;
-  const int *body_pathseg;           /* [nbody][4] runs of consecutive dofs on the path root -> body: begin | end << 8 (0 = none) */
+  const int *body_pathseg;           /* [nbody][8]: 4 runs of consecutive dofs on the path root -> body, then 4 runs of
+                                        consecutive ancestor bodies (incl. the body): begin | end << 8 (0 = none) */
   const unsigned char* jump; /* [jump_rounds][nbody]: 2^r-th ancestor body, 0 = none */
   const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
   // joints
