@@ -1024,16 +1024,23 @@ struct EnvWave {
         if (k != vreal(0.)) s[L.smooth + m.jnt_dofadr[j]] -= k * (s[L.qpos + m.jnt_qposadr[j]] - m.jnt_springref[j]);
       }
     }
-    VNL_SERIAL {  // several actuators may drive one dof: keep the accumulation ordered
-      for (int i = 0; i < m.nu; i++) {
-        vreal ctrl = s[L.ctrl + i], a = ctrl;
-        vreal tau = m.act_tau[i];
-        if (tau >= vreal(0.)) {
-          a = s[L.act + i];
-          s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
-        }
-        s[qa_tmp + m.act_dof[i]] += m.act_gear[i] * m.act_gain[i] * a;
+    // Actuator forces in parallel (the model tables are L2 reads: the former one-lane loop paid 30 latencies in a
+    // row); only the ordered accumulation into the dofs -- several actuators may drive one dof -- stays serial, on
+    // LDS values.
+    const int frc = L.tmp2, adof = L.tmp;  // both free here
+    VNL_FOR(i, m.nu) {
+      vreal ctrl = s[L.ctrl + i], a = ctrl;
+      vreal tau = m.act_tau[i];
+      if (tau >= vreal(0.)) {
+        a = s[L.act + i];
+        s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
       }
+      s[frc + i] = m.act_gear[i] * m.act_gain[i] * a;
+      s[adof + i] = vreal(m.act_dof[i]);  // exact: dof < 2^24
+    }
+    VNL_SYNC();
+    VNL_SERIAL {
+      for (int i = 0; i < m.nu; i++) s[qa_tmp + (int)s[adof + i]] += s[frc + i];
     }
     VNL_SYNC();
     vreal* gf = gqfrc_act();

@@ -560,6 +560,10 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
     vnl_env_destroy(env);
     return fail(VNL_ERR_UNSUPPORTED, "more than 85 bodies (in-place tree prefix keeps 8 elements per lane)");
   }
+  if (d.nu > d.nv) {
+    vnl_env_destroy(env);
+    return fail(VNL_ERR_UNSUPPORTED, "more actuators than dofs (the actuator forces are staged in two dof vectors)");
+  }
   if (d.nefc > 512) {
     vnl_env_destroy(env);
     return fail(VNL_ERR_UNSUPPORTED, "more than 512 constraint rows (line-search rows are register-resident)");
