@@ -11,6 +11,10 @@
  *                       (+ PipelineEnv.pipeline_step = n_frames x mjx.step, rodent.py:181)
  *   vnl_policy_*   <->  make_inference_fn(...).policy reference ppo_imitation/ppo_networks.py:45-83
  *                       IntentionNetwork.__call__     reference ppo_imitation/intention_policy_network.py:91-105
+ *   vnl_rollout_post <-> brax Episode/AutoReset wrappers (train.py:204-214) + Transition of actor_step (acting.py:34-57)
+ *   vnl_gather_rows / vnl_ppo_head / vnl_adam_step
+ *                  <->  the minibatch gather, loss head (intention_losses.py:26-87,131-202) and optimiser update of one
+ *                       PPO minibatch step (ppo_imitation/train.py:231-291)
  *
  * Conventions
  *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
