@@ -246,6 +246,7 @@ struct EnvWave {
   VNL_HD int madr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[d]; }            // first entry of row d
   VNL_HD int eadr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[m.nv + d]; }     // madr(d) + depth(d)
   VNL_HD int depth(int d) const { return eadr(d) - madr(d); }
+  VNL_HD int ndesc(int d) const { return ((const unsigned short*)(s + L.tab_madr))[2 * m.nv + d]; }       // descendants of dof d
   VNL_HD int parent_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[b]; }
   VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
   VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
@@ -260,7 +261,10 @@ struct EnvWave {
     unsigned char* ta = (unsigned char*)(s + L.tab_anc);
     VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
     unsigned short* tm = (unsigned short*)(s + L.tab_madr);
-    VNL_FOR(d, m.nv) tm[d] = (unsigned short)m.dof_Madr[d], tm[m.nv + d] = (unsigned short)(m.dof_Madr[d] + m.dof_depth[d]);
+    VNL_FOR(d, m.nv) {
+      tm[d] = (unsigned short)m.dof_Madr[d], tm[m.nv + d] = (unsigned short)(m.dof_Madr[d] + m.dof_depth[d]);
+      tm[2 * m.nv + d] = (unsigned short)m.dof_ndesc[d];
+    }
     unsigned char* tb = (unsigned char*)(s + L.tab_body);
     VNL_FOR(b, m.nbody) {
       tb[b] = (unsigned char)m.body_parent[b];
@@ -643,7 +647,7 @@ struct EnvWave {
       int a = (int)lane + q * VNL_LANES;
       bool ok = a < m.nv;
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
-      dep[q] = d, last[q] = ok ? a + m.dof_ndesc[a] : -1;
+      dep[q] = d, last[q] = ok ? a + ndesc(a) : -1;
       dg[q] = ok ? s[L.LD + adr] : vreal(1.);
 #pragma unroll
       for (int c = 0; c < MAXD; c++)
@@ -902,7 +906,7 @@ struct EnvWave {
   // out[a] = (in[a] + sum_{i in desc(a)} A(i, a) in[i]) (* or / D); descendants are the next ndesc dofs
   VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/) const {
     VNL_FOR(a, m.nv) {
-      int da = eadr(a) - madr(a), nd = m.dof_ndesc[a];
+      int da = eadr(a) - madr(a), nd = ndesc(a);
       vreal acc = s[in + a];
       const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
       const vreal* ld = s + L.LD - da;

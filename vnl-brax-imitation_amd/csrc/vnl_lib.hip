@@ -476,7 +476,7 @@ static void layout(vnl_env* env) {
   L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv), L.search = sec("search", d.nv);
   L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv), L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv);
   L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncg);
-  L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(4 * (size_t)d.nv));
+  L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(6 * (size_t)d.nv));  // row start | row end | descendants, 16 bit each
   L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
   L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
