@@ -114,15 +114,15 @@ VNL_HD float vnl_recip(float x) {
 #ifdef VNL_PROFILE
 #define VNL_NPROF 40
 __device__ unsigned long long g_vnl_prof[VNL_NPROF];
-// lane 0 keeps the running sums in LDS (section "prof", reserved in this build only); slot VNL_NPROF = last stamp
-#define VNL_PROF(i)                                                      \
-  do {                                                                   \
-    if (lane == 0) {                                                     \
-      unsigned long long* p_ = (unsigned long long*)(s + L.prof);        \
-      unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
-      p_[i] += t_ - p_[VNL_NPROF];                                       \
-      p_[VNL_NPROF] = __builtin_amdgcn_s_memtime();                      \
-    }                                                                    \
+// lane 0 keeps the running sums in LDS (section "prof", reserved in this build only) as floats (a substep is < 2^24
+// clocks); slot VNL_NPROF = low word of the last stamp
+#define VNL_PROF(i)                                                                             \
+  do {                                                                                          \
+    if (lane == 0) {                                                                            \
+      unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                     \
+      s[L.prof + (i)] += (float)(t_ - __builtin_bit_cast(unsigned, (float)s[L.prof + VNL_NPROF])); \
+      s[L.prof + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime()); \
+    }                                                                                           \
   } while (0)
 #else
 #define VNL_PROF(i)
@@ -190,16 +190,13 @@ struct EnvWave {
 #ifdef VNL_PROFILE
   VNL_HD void prof_begin() const {
     if (lane == 0) {
-      unsigned long long* p_ = (unsigned long long*)(s + L.prof);
-      for (int i = 0; i < VNL_NPROF; i++) p_[i] = 0;
-      p_[VNL_NPROF] = __builtin_amdgcn_s_memtime();
+      for (int i = 0; i < VNL_NPROF; i++) s[L.prof + i] = 0.f;
+      s[L.prof + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
     }
   }
   VNL_HD void prof_end() const {
-    if (lane == 0) {
-      unsigned long long* p_ = (unsigned long long*)(s + L.prof);
-      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], p_[i]);
-    }
+    if (lane == 0)
+      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], (unsigned long long)s[L.prof + i]);
   }
 #else
   VNL_HD void prof_begin() const {}
