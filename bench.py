@@ -137,6 +137,8 @@ def main() -> None:
                 tm.k += 1
             return orig_step(st_, a_)
 
+        extra = ("traj",) if args.no_autoreset else ("truncation", "traj")  # truncation comes from EpisodeWrapper
+
         def run(k0, n, timed):
             nonlocal state
             tm.k = 0 if timed else None
@@ -144,7 +146,7 @@ def main() -> None:
             done = 0
             while done < n:
                 chunk = min(unroll, n - done)
-                state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=("truncation", "traj"))
+                state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=extra)
                 done += chunk
             base.step = orig_step
     torch.cuda.synchronize(dev)

@@ -71,6 +71,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_ROWGETF(expr, q, l) (expr)
 #define VNL_WAVE_FENCE()
 #define VNL_COUNT(pred) ((pred) ? 1 : 0)
+#define VNL_RANK(pred, run, rank) do { rank = run; if (pred) run++; } while (0)
 #define VNL_LINE_HEADERS(out, base, stride) \
   do { for (int k_ = 0; k_ < VNL_FAC_LINES; k_++) out[k_] = (int)(base)[k_ * (stride)]; } while (0)
 #define VNL_UNIFORM_I(x) (x)

@@ -8,7 +8,10 @@ import json
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {1: "kin+inertia+M+factor+invert", 2: "kinematics", 3: "kin+inertia+M", 4: "kin+inertia+M+factor",
-         5: "kin+inertia+bias", 6: "twists+Jv", 7: "solve (M^-1 x)", 8: "ls row pass (3 alphas)"}
+         5: "kin+inertia+bias", 6: "twists+Jv", 7: "solve (M^-1 x)", 8: "ls row pass (3 alphas)",
+         18: "subtree sums (10 wide)", 19: "body inertias"}
+if os.environ.get("STAGES"):
+    NAMES = {int(k): NAMES.get(int(k), "?") for k in os.environ["STAGES"].split()}
 
 
 def run(stage, count):
@@ -16,7 +19,10 @@ def run(stage, count):
     if count:
         env["VNL_DBG_REPEAT"] = f"{stage}:{count}"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2",
-                          "--no-cpu-baseline", "--no-autoreset"], env=env, capture_output=True, text=True).stdout
+                          "--no-cpu-baseline", "--no-autoreset", "--random-actions"], env=env, capture_output=True, text=True)
+    if out.returncode != 0 or not out.stdout.strip():
+        sys.exit("bench.py failed:\n" + out.stderr[-3000:])
+    out = out.stdout
     return json.loads(out.strip().splitlines()[-1])["roofline"]["kernel_ms"]
 
 

@@ -101,6 +101,13 @@ VNL_HD float vnl_wave_scan(float x) {
     _Pragma("unroll") for (int k_ = 0; k_ < VNL_FAC_LINES; k_++) out[k_] = __builtin_amdgcn_readlane(hv_, k_); \
   } while (0)
 #define VNL_COUNT(pred) __popcll(__ballot(pred))                  /* lanes (items) for which pred holds */
+/* stream compaction: rank = run + number of earlier items with pred; run += their total (run stays wave-uniform) */
+#define VNL_RANK(pred, run, rank)                                                   \
+  do {                                                                              \
+    const unsigned long long b_ = __ballot(pred);                                   \
+    rank = run + (int)__popcll(b_ & ((1ull << (threadIdx.x & 63)) - 1ull));         \
+    run += (int)__popcll(b_);                                                       \
+  } while (0)
 #define VNL_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)        /* a value known to be the same in every lane */
 // 1/x: v_rcp_f32 (1 ulp) + one Newton step instead of the ~10-instruction IEEE division
 VNL_HD float vnl_recip(float x) {
@@ -449,12 +456,60 @@ struct EnvWave {
     VNL_SYNC();
   }
 
-  // sum children into parents, one lane per component (serial over bodies within a lane)
+  // Subtree sums (children into parents), one lane per component, bodies from the last to the first.  A child that
+  // directly follows its parent in the numbering (a chain link: most links of a depth-first numbering) hands its
+  // sum over in a REGISTER; only a child at a branching point adds into its parent through LDS.  (The plain form
+  // `s[parent] += s[b]` made every one of the ~64 steps a dependent LDS read-modify-write.)
   VNL_HD void tree_accumulate(int base, int width) const {
     VNL_FOR(k, width) {
-      for (int b = m.nbody - 1; b > 1; b--) {
-        int p = parent_of(b);
-        if (p > 0) s[base + width * p + k] += s[base + width * b + k];
+      vreal carry = vreal(0.);
+      int b = m.nbody - 1;
+      constexpr int G = 8;  // bodies per trip
+      for (; b >= 1 && (b & (G - 1)) != G - 1; b--) {  // down to a group boundary
+        const int o = base + width * b + k;
+        const vreal v = s[o] + carry;
+        const int p = parent_of(b);
+        if (carry != vreal(0.)) s[o] = v;
+        if (p == b - 1) {
+          carry = v;
+        } else {
+          carry = vreal(0.);
+          if (p > 0) s[base + width * p + k] += v;
+        }
+      }
+      // G bodies per trip: their values and their parent bytes arrive in ONE LDS round trip; links inside the
+      // group stay in registers, so only a branch child whose parent lies below the group pays another one.
+      for (; b >= G - 1; b -= G) {
+        const int b0 = b - (G - 1);
+        const int o = base + width * b0 + k;
+        unsigned pw[G / 4];
+#pragma unroll
+        for (int j = 0; j < G / 4; j++) pw[j] = (unsigned)VNL_UNIFORM_I((int)((const unsigned*)(s + L.tab_body))[(b0 >> 2) + j]);
+        vreal x[G], x0[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) x0[j] = x[j] = s[o + width * j];
+#pragma unroll
+        for (int j = G - 1; j >= 0; j--) {
+          const int bb = b0 + j;
+          if (bb >= 1) {
+            const int p = (int)((pw[j >> 2] >> (8 * (j & 3))) & 255u);
+            const vreal v = x[j] + carry;
+            if (v != x0[j]) s[o + width * j] = v;
+            if (p == bb - 1) {
+              carry = v;
+            } else {
+              carry = vreal(0.);
+              bool inside = false;
+#pragma unroll
+              for (int t = 0; t < G; t++)
+                if (t < j - 1 && p == b0 + t) {
+                  x[t] += v;
+                  inside = true;
+                }
+              if (!inside && p > 0) s[base + width * p + k] += v;
+            }
+          }
+        }
       }
     }
     VNL_SYNC();
@@ -1016,9 +1071,6 @@ struct EnvWave {
 
   // passive + actuation + qfrc_smooth + qacc_smooth
   VNL_HD void smooth_forces() const {
-    const int qa_tmp = L.Ma;  // free until the solver starts
-    VNL_FOR(d, m.nv) s[qa_tmp + d] = vreal(0.);
-    VNL_SYNC();
     VNL_FOR(j, m.njnt) {
       if (m.jnt_type[j] == VNL_JNT_HINGE) {
         vreal k = m.jnt_stiffness[j];
@@ -1026,8 +1078,9 @@ struct EnvWave {
       }
     }
     // Actuator forces in parallel (the model tables are L2 reads: the former one-lane loop paid 30 latencies in a
-    // row); only the ordered accumulation into the dofs -- several actuators may drive one dof -- stays serial, on
-    // LDS values.
+    // row).  Several actuators may drive one dof, so each dof's lane then walks the actuator list in order and
+    // keeps the forces aimed at it: broadcast LDS reads that pipeline, where one lane adding into the dofs paid a
+    // dependent read-modify-write per actuator.
     const int frc = L.tmp2, adof = L.tmp;  // both free here
     VNL_FOR(i, m.nu) {
       vreal ctrl = s[L.ctrl + i], a = ctrl;
@@ -1040,13 +1093,15 @@ struct EnvWave {
       s[adof + i] = vreal(m.act_dof[i]);  // exact: dof < 2^24
     }
     VNL_SYNC();
-    VNL_SERIAL {
-      for (int i = 0; i < m.nu; i++) s[qa_tmp + (int)s[adof + i]] += s[frc + i];
-    }
-    VNL_SYNC();
     vreal* gf = gqfrc_act();
     VNL_FOR(d, m.nv) {
-      vreal fa = s[qa_tmp + d];
+      vreal fa = vreal(0.);
+      const vreal me = vreal(d);
+#pragma unroll 6
+      for (int i = 0; i < m.nu; i++) {
+        const vreal f = s[frc + i];
+        if (s[adof + i] == me) fa += f;
+      }
       gf[d] = fa;
       vreal v = s[L.smooth + d] + fa;
       s[L.smooth + d] = v;
@@ -1158,12 +1213,16 @@ struct EnvWave {
       }
     }
     VNL_SYNC();
-    VNL_SERIAL {  // list of contacts with D != 0 (typically a handful of the 59)
+    {  // list of contacts with D != 0 (typically a handful of the 59), in contact order
       unsigned char* act = (unsigned char*)(s + L.act_list);
       int na = 0;
-      for (int c = 0; c < m.ncon; c++)
-        if (s[L.efc_D + m.nlimit + 4 * c] != vreal(0.)) act[na++] = (unsigned char)c;
-      ((int*)(s + L.act_list))[(m.ncon + 3) / 4] = na;
+      VNL_FOR(c, VNL_PAD_ITEMS(m.ncon)) {
+        const bool on = c < m.ncon && s[L.efc_D + m.nlimit + 4 * (c < m.ncon ? c : 0)] != vreal(0.);
+        int pos;
+        VNL_RANK(on, na, pos);
+        if (on) act[pos] = (unsigned char)c;
+      }
+      VNL_SERIAL { ((int*)(s + L.act_list))[(m.ncon + 3) / 4] = na; }
     }
     VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
     VNL_SYNC();
@@ -1519,6 +1578,10 @@ struct EnvWave {
         body_inertias(false);
         mass_matrix(vreal(0.));
         factor(false);
+      } else if (m.dbg_stage == 18) {
+        tree_accumulate(L.P, 10);
+      } else if (m.dbg_stage == 19) {
+        body_inertias(false);
       }
     }
 #endif
