@@ -42,8 +42,9 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 
 
-def cpu_baseline(env, num_envs: int, steps: int, seed: int = 1) -> dict:
-    """Time the CPU oracle (float32 build, OpenMP over envs) on a bounded sample of the same workload."""
+def cpu_baseline(env, num_envs: int, max_steps: int = 200, budget_s: float = 12.0, seed: int = 1) -> dict:
+    """Time the CPU oracle (float32 build, OpenMP over envs) on a bounded sample of the same workload: control
+    steps of `num_envs` envs until `budget_s` seconds of CPU work are spent (at most `max_steps`)."""
     import helpers as H
 
     o = H.make_oracle(env, "f32")
@@ -51,11 +52,15 @@ def cpu_baseline(env, num_envs: int, steps: int, seed: int = 1) -> dict:
     sf = rng.integers(0, 235, num_envs).astype(np.int32)
     noise = (1e-3 * rng.standard_normal((num_envs, 74))).astype(np.float32)
     st = o.env_reset(sf, noise)
-    acts = np.clip(0.3 * rng.standard_normal((steps, num_envs, 30)), -1, 1).astype(np.float32)
+    acts = np.clip(0.3 * rng.standard_normal((max_steps, num_envs, 30)), -1, 1).astype(np.float32)
     o.env_step(st, acts[0])  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
-    for k in range(steps):
-        o.env_step(st, acts[k])
+    steps = 0
+    while steps < max_steps:
+        o.env_step(st, acts[steps])
+        steps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
     dt = time.perf_counter() - t0
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return dict(value=num_envs * steps / dt, unit="env-steps/s", cores=cores, kind="port",
@@ -223,7 +228,7 @@ def main() -> None:
             "finite": finite,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(base, num_envs=1024, steps=10)
+            out["cpu_baseline"] = cpu_baseline(base, num_envs=1024)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
