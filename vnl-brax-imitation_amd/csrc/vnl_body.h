@@ -187,11 +187,19 @@ VNL_HD vreal dot(S6 p, S6 q) { return dot(p.a, q.a) + dot(p.l, q.l); }
 VNL_HD S6 mcross(S6 u, S6 v) { return S6{cross(u.a, v.a), cross(u.l, v.a) + cross(u.a, v.l)}; }
 VNL_HD S6 mcross_force(S6 v, S6 f) { return S6{cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
 
+// constant address space of the kernel-constant block (scalar loads, never clobbered); nothing special on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VNL_CAS __attribute__((address_space(4)))
+#define VNL_TO_CAS(T, p) ((const VNL_CAS T*)(unsigned long long)(p))
+#else
+#define VNL_CAS
+#define VNL_TO_CAS(T, p) ((const T*)(p))
+#endif
 struct EnvWave {
-  const DevModel& m;
-  const DevEnv& ev;
+  const VNL_CAS DevModel& m;
+  const VNL_CAS DevEnv& ev;
   const DevState& st;
-  const WsLayout& L;
+  const VNL_CAS WsLayout& L;
   vreal* s;  // LDS
   unsigned e, lane;
 #ifdef VNL_PROFILE

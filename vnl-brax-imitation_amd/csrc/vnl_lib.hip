@@ -106,6 +106,7 @@ struct vnl_env {
   DevModel dm{};
   DevEnv de{};
   WsLayout L{};
+  KernelConsts* kc = nullptr;  // device copy of {dm, de, L}
   vreal* dump = nullptr;  // [B][L.total] image of the per-env LDS, written only when debug is on
   int debug = 0;
   size_t lds_bytes = 0;
@@ -488,7 +489,7 @@ static void layout(vnl_env* env) {
   L.total = (o + 3) & ~3;
 }
 
-__global__ void vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L, const vreal* action, vreal* dump);
+__global__ void vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action, vreal* dump);
 
 extern "C" void vnl_env_destroy(vnl_env* env) {
   if (!env) return;
@@ -577,6 +578,14 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, vnl_step_kernel, 64, env->lds_bytes) == hipSuccess)
       env->blocks_per_cu = nb_;
   }
+  {
+    KernelConsts host{env->dm, env->de, env->L};
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(KernelConsts)));
+    env->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, &host, sizeof(KernelConsts), hipMemcpyHostToDevice));
+    env->kc = (KernelConsts*)p;
+  }
   *out = env;
   return VNL_OK;
 }
@@ -617,18 +626,20 @@ extern "C" int vnl_env_debug(vnl_env* env, int32_t enable, int32_t* row_stride) 
 // ----------------------------------------------------------------------------- kernels
 // One env per 64-lane workgroup; the env's whole working set lives in dynamic LDS (~25 KB ->
 // 6 workgroups per CU, 1536 envs in flight on 256 CUs).
-__global__ void __launch_bounds__(64) vnl_step_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L,
-                                                      const vreal* action, vreal* dump) {
+__global__ void __launch_bounds__(64) vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action,
+                                                      vreal* dump) {
   VNL_LDS_DECL(lds);
-  EnvWave w{m, ev, st, L, lds, blockIdx.x, threadIdx.x};
+  const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x};
   w.step(action);
   if (dump) w.dump(dump);
 }
 
-__global__ void __launch_bounds__(64) vnl_reset_kernel(DevModel m, DevEnv ev, DevState st, WsLayout L,
-                                                       const int* start_frame, const vreal* noise, vreal* dump) {
+__global__ void __launch_bounds__(64) vnl_reset_kernel(const KernelConsts* kc, DevState st, const int* start_frame,
+                                                       const vreal* noise, vreal* dump) {
   VNL_LDS_DECL(lds);
-  EnvWave w{m, ev, st, L, lds, blockIdx.x, threadIdx.x};
+  const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x};
   w.reset(start_frame, noise);
   if (dump) w.dump(dump);
 }
@@ -655,8 +666,8 @@ extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const flo
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
-  hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream, env->dm, env->de,
-                     ds, env->L, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr);
+  hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                     (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }
@@ -666,8 +677,8 @@ extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* 
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
-  hipLaunchKernelGGL(vnl_step_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream, env->dm, env->de,
-                     ds, env->L, (const vreal*)action, env->debug ? env->dump : nullptr);
+  hipLaunchKernelGGL(vnl_step_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                     (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug ? env->dump : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

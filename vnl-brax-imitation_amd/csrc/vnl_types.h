@@ -90,3 +90,13 @@ struct WsLayout {
   int act_list;         /* ncon bytes: contacts with D != 0, then their count (int) */
   int total;
 };
+
+/* Everything the env kernels read that does not change between launches, in one device buffer.  The kernels read
+ * it through the CONSTANT address space (scalar loads at the point of use) instead of taking ~350 SGPRs' worth of
+ * by-value kernel arguments, which the compiler kept alive across the whole kernel by spilling them to VGPR lanes. */
+struct KernelConsts {
+  DevModel m;
+  DevEnv ev;
+  WsLayout L;
+};
+
