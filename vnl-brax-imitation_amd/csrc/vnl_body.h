@@ -191,9 +191,11 @@ VNL_HD S6 mcross_force(S6 v, S6 f) { return S6{cross(v.a, f.a) + cross(v.l, f.l)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define VNL_CAS __attribute__((address_space(4)))
 #define VNL_TO_CAS(T, p) ((const VNL_CAS T*)(unsigned long long)(p))
+#define VNL_LAUNDER(p) asm volatile("" : "+s"(p))
 #else
 #define VNL_CAS
 #define VNL_TO_CAS(T, p) ((const T*)(p))
+#define VNL_LAUNDER(p)
 #endif
 struct EnvWave {
   const VNL_CAS DevModel& m;
@@ -202,6 +204,15 @@ struct EnvWave {
   const VNL_CAS WsLayout& L;
   vreal* s;  // LDS
   unsigned e, lane;
+  const VNL_CAS KernelConsts* kc;
+  // The same view with the constant block's address made opaque to the optimiser: constants read by the stage that
+  // follows are loaded there (scalar loads) instead of being kept alive -- spilled to VGPR lanes and fetched back
+  // with v_readlane -- from the top of the kernel.
+  VNL_HD EnvWave fresh() const {
+    const VNL_CAS KernelConsts* k = kc;
+    VNL_LAUNDER(k);
+    return EnvWave{k->m, k->ev, st, k->L, s, e, lane, k};
+  }
 #ifdef VNL_PROFILE
   VNL_HD void prof_begin() const {
     if (lane == 0) {
@@ -1593,20 +1604,20 @@ struct EnvWave {
       }
     }
 #endif
-    kinematics();
+    fresh().kinematics();
     VNL_PROF(0);
-    body_inertias(true);
+    fresh().body_inertias(true);
     VNL_PROF(1);
-    int cvel = bias_forces();
-    mass_matrix(vreal(0.));
-    factor();
-    mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
+    int cvel = fresh().bias_forces();
+    fresh().mass_matrix(vreal(0.));
+    fresh().factor();
+    fresh().mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
     VNL_PROF(10);
-    invert_factor();
+    fresh().invert_factor();
     VNL_PROF(11);
-    smooth_forces();
+    fresh().smooth_forces();
     VNL_PROF(12);
-    make_constraint(cvel);
+    fresh().make_constraint(cvel);
     VNL_PROF(13);
 #ifdef VNL_STAGE_KNOBS
     for (int rep = 0; rep < m.dbg_count; rep++) {
@@ -1643,7 +1654,7 @@ struct EnvWave {
       }
     }
 #endif
-    solve();
+    fresh().solve();
   }
 
   // forward.euler + _advance; leaves qacc (warm start) in L.qacc and the new state in L.qpos/qvel/act

@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(64) vnl_step_kernel(const KernelConsts* kc, De
                                                       vreal* dump) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x};
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k};
   w.step(action);
   if (dump) w.dump(dump);
 }
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(64) vnl_reset_kernel(const KernelConsts* kc, D
                                                        const vreal* noise, vreal* dump) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x};
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k};
   w.reset(start_frame, noise);
   if (dump) w.dump(dump);
 }
