@@ -1462,17 +1462,17 @@ struct EnvWave {
     const int nv = m.nv, ne = m.nefc;
     // --- warm start selection: cost at qacc_warmstart vs qacc_smooth.
     // On entry: Jaref holds -aref (make_constraint), mv holds M*warm, qacc holds warm (forward()).
-    jac_mul(L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
-    vreal cost_s = constraint_cost(L.Jaref);  // gauss term vanishes: M qacc_smooth = qfrc_smooth
+    fresh().jac_mul(L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
+    vreal cost_s = fresh().constraint_cost(L.Jaref);  // gauss term vanishes: M qacc_smooth = qfrc_smooth
     VNL_FOR(d, nv) s[L.tmp + d] = s[L.qacc + d] - s[L.qacc_smooth + d];
     VNL_SYNC();
-    jac_mul(L.tmp, L.jv, false);  // J (warm - smooth)
+    fresh().jac_mul(L.tmp, L.jv, false);  // J (warm - smooth)
     VNL_FOR(r, ne) s[L.jv + r] += s[L.Jaref + r];  // Jaref(warm)
     vreal gw = vreal(0.);
     VNL_FOR(d, nv) gw += (s[L.mv + d] - s[L.smooth + d]) * s[L.tmp + d];
     gw = vnl_wave_sum(gw);
     VNL_SYNC();
-    vreal cost_w = constraint_cost(L.jv) + vreal(0.5) * gw;
+    vreal cost_w = fresh().constraint_cost(L.jv) + vreal(0.5) * gw;
     bool use_warm = cost_w < cost_s;
     VNL_FOR(d, nv) {
       s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
@@ -1484,14 +1484,14 @@ struct EnvWave {
     VNL_SYNC();
     VNL_PROF(14);
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
-    vreal cost = constraint_force() + gauss;
+    vreal cost = fresh().constraint_force() + gauss;
     vreal prev_cost = INFINITY;
     VNL_FOR(d, nv) {
       vreal g = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
       s[L.grad + d] = g, s[L.Mgrad + d] = g;
     }
     VNL_SYNC();
-    solve_inplace(L.Mgrad);
+    fresh().solve_inplace(L.Mgrad);
     VNL_FOR(d, nv) {
       s[L.search + d] = -s[L.Mgrad + d];
       s[L.mv + d] = -s[L.grad + d];  // M search
@@ -1507,7 +1507,7 @@ struct EnvWave {
       vreal smag = sqrt(vdot(L.search, L.search)) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
       VNL_PROF(16);
-      jac_mul(L.search, L.jv, false);
+      fresh().jac_mul(L.search, L.jv, false);
       VNL_PROF(17);
       vreal qg1 = vreal(0.), qg2 = vreal(0.);
       VNL_FOR(d, nv) {
@@ -1517,8 +1517,8 @@ struct EnvWave {
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(18);
-      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol)
-                                              : line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol);
+      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol)
+                                              : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol);
       VNL_FOR(d, nv) {
         s[L.qacc + d] += alpha * s[L.search + d];
         s[L.Ma + d] += alpha * s[L.mv + d];
@@ -1533,7 +1533,7 @@ struct EnvWave {
       VNL_FOR(d, nv) g += (s[L.Ma + d] - s[L.smooth + d]) * (s[L.qacc + d] - s[L.qacc_smooth + d]);
       g = vnl_wave_sum(g);
       VNL_PROF(21);
-      vreal ncost = constraint_force() + vreal(0.5) * g;
+      vreal ncost = fresh().constraint_force() + vreal(0.5) * g;
       VNL_PROF(22);
       prev_cost = cost, cost = ncost, gauss = vreal(0.5) * g;
       vreal d1 = vreal(0.);
@@ -1545,7 +1545,7 @@ struct EnvWave {
       d1 = vnl_wave_sum(d1);
       VNL_SYNC();
       VNL_PROF(23);
-      solve_inplace(L.tmp);
+      fresh().solve_inplace(L.tmp);
       VNL_PROF(24);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
@@ -1664,13 +1664,13 @@ struct EnvWave {
     VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
     VNL_SYNC();
     if (m.eulerdamp) {
-      body_inertias(false);
+      fresh().body_inertias(false);
       VNL_PROF(1);
-      mass_matrix(m.dt);
-      if (!factor_solve(L.tmp)) {
-        factor();
-        invert_factor();
-        solve_inplace(L.tmp);
+      fresh().mass_matrix(m.dt);
+      if (!fresh().factor_solve(L.tmp)) {
+        fresh().factor();
+        fresh().invert_factor();
+        fresh().solve_inplace(L.tmp);
       }
       VNL_PROF(27);
     }
@@ -1869,8 +1869,8 @@ struct EnvWave {
     const vreal* gw = st.warm + (size_t)e * m.nv;
     VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
-      forward(f == 0 ? gw : s + L.qacc);
-      euler();
+      fresh().forward(f == 0 ? gw : s + L.qacc);
+      fresh().euler();
     }
     int new_frame = old_frame + 1, new_sub = old_sub + 1;
     int fo = clampi(old_frame, 0, ev.T - 1), nj = m.nq - 7;
