@@ -1,4 +1,5 @@
-// Device-side tables passed to the kernels BY VALUE (kernarg segment).
+// Device-side tables of the env kernels (DevModel, DevEnv, WsLayout: uploaded once as one KernelConsts block and read
+// through the constant address space; DevState: the caller's buffers, by value).
 #pragma once
 #include <stdint.h>
 
