@@ -43,6 +43,7 @@
 #define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
 #define VNL_ROWS_SMALL 5    /* specialisation for nefc <= 320 (the rodent has 303) */
 #define VNL_PREFIX_PER_LANE 8 /* 6 * nbody <= 512 elements per in-place tree prefix */
+#define VNL_CHAIN_WIDTH 8 /* entries of a sparse row / column fetched per trip of row_dot / col_apply */
 #define VNL_ROWSETS_1 1 /* matrix rows a lane keeps in registers while factorising: nv <= 64 .. */
 #define VNL_ROWSETS_2 2 /* .. or nv <= 128 */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
@@ -950,18 +951,39 @@ struct EnvWave {
     const vreal* row = s + L.LD + adr;
     vreal acc = vreal(0.);
     int t = 1;
-    for (; t + 7 <= dep; t += 8) {  // eight independent index->value chains per trip: two LDS round trips
-      int j0 = an[t], j1 = an[t + 1], j2 = an[t + 2], j3 = an[t + 3], j4 = an[t + 4], j5 = an[t + 5], j6 = an[t + 6], j7 = an[t + 7];
-      vreal l0 = row[t], l1 = row[t + 1], l2 = row[t + 2], l3 = row[t + 3], l4 = row[t + 4], l5 = row[t + 5], l6 = row[t + 6], l7 = row[t + 7];
-      acc += (l0 * s[in + j0] + l1 * s[in + j1] + l2 * s[in + j2] + l3 * s[in + j3]) +
-             (l4 * s[in + j4] + l5 * s[in + j5] + l6 * s[in + j6] + l7 * s[in + j7]);
+    constexpr int W = VNL_CHAIN_WIDTH;  // independent index->value chains per trip: two LDS round trips per trip
+    for (; t + W - 1 <= dep; t += W) {
+      int j[W];
+      vreal l[W], x[W];
+#pragma unroll
+      for (int u = 0; u < W; u++) j[u] = an[t + u];
+#pragma unroll
+      for (int u = 0; u < W; u++) l[u] = row[t + u];
+#pragma unroll
+      for (int u = 0; u < W; u++) x[u] = s[in + j[u]];
+      vreal p0 = vreal(0.), p1 = vreal(0.);
+#pragma unroll
+      for (int u = 0; u < W; u += 2) p0 += l[u] * x[u], p1 += l[u + 1] * x[u + 1];
+      acc += p0 + p1;
     }
-    for (; t + 3 <= dep; t += 4) {
-      int j0 = an[t], j1 = an[t + 1], j2 = an[t + 2], j3 = an[t + 3];
-      vreal l0 = row[t], l1 = row[t + 1], l2 = row[t + 2], l3 = row[t + 3];
-      acc += l0 * s[in + j0] + l1 * s[in + j1] + l2 * s[in + j2] + l3 * s[in + j3];
+    if (t <= dep) {  // the remainder in ONE predicated trip (4-wide and single-entry tails cost a trip each)
+      int j[W];
+      vreal l[W], x[W];
+#pragma unroll
+      for (int u = 0; u < W; u++) {
+        const int tt = t + u <= dep ? t + u : dep;
+        j[u] = an[tt], l[u] = row[tt];
+      }
+#pragma unroll
+      for (int u = 0; u < W; u++) x[u] = s[in + j[u]];
+      vreal p0 = vreal(0.), p1 = vreal(0.);
+#pragma unroll
+      for (int u = 0; u < W; u += 2) {
+        p0 += t + u <= dep ? l[u] * x[u] : vreal(0.);
+        p1 += t + u + 1 <= dep ? l[u + 1] * x[u + 1] : vreal(0.);
+      }
+      acc += p0 + p1;
     }
-    for (; t <= dep; t++) acc += row[t] * s[in + an[t]];
     return acc;
   }
 
@@ -982,18 +1004,39 @@ struct EnvWave {
       const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
       const vreal* ld = s + L.LD - da;
       int i = a + 1, iend = a + nd;
-      for (; i + 7 <= iend; i += 8) {
-        int e0 = ea[i], e1 = ea[i + 1], e2 = ea[i + 2], e3 = ea[i + 3], e4 = ea[i + 4], e5 = ea[i + 5], e6 = ea[i + 6], e7 = ea[i + 7];
-        vreal x0 = s[in + i], x1 = s[in + i + 1], x2 = s[in + i + 2], x3 = s[in + i + 3];
-        vreal x4 = s[in + i + 4], x5 = s[in + i + 5], x6 = s[in + i + 6], x7 = s[in + i + 7];
-        acc += (ld[e0] * x0 + ld[e1] * x1 + ld[e2] * x2 + ld[e3] * x3) + (ld[e4] * x4 + ld[e5] * x5 + ld[e6] * x6 + ld[e7] * x7);
+      constexpr int W = VNL_CHAIN_WIDTH;
+      for (; i + W - 1 <= iend; i += W) {
+        int e[W];
+        vreal l[W], x[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) e[u] = ea[i + u];
+#pragma unroll
+        for (int u = 0; u < W; u++) x[u] = s[in + i + u];
+#pragma unroll
+        for (int u = 0; u < W; u++) l[u] = ld[e[u]];
+        vreal p0 = vreal(0.), p1 = vreal(0.);
+#pragma unroll
+        for (int u = 0; u < W; u += 2) p0 += l[u] * x[u], p1 += l[u + 1] * x[u + 1];
+        acc += p0 + p1;
       }
-      for (; i + 3 <= iend; i += 4) {
-        int e0 = ea[i], e1 = ea[i + 1], e2 = ea[i + 2], e3 = ea[i + 3];
-        vreal x0 = s[in + i], x1 = s[in + i + 1], x2 = s[in + i + 2], x3 = s[in + i + 3];
-        acc += ld[e0] * x0 + ld[e1] * x1 + ld[e2] * x2 + ld[e3] * x3;
+      if (i <= iend) {  // the remainder in one predicated trip
+        int e[W];
+        vreal l[W], x[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+          const int ii = i + u <= iend ? i + u : iend;
+          e[u] = ea[ii], x[u] = s[in + ii];
+        }
+#pragma unroll
+        for (int u = 0; u < W; u++) l[u] = ld[e[u]];
+        vreal p0 = vreal(0.), p1 = vreal(0.);
+#pragma unroll
+        for (int u = 0; u < W; u += 2) {
+          p0 += i + u <= iend ? l[u] * x[u] : vreal(0.);
+          p1 += i + u + 1 <= iend ? l[u + 1] * x[u + 1] : vreal(0.);
+        }
+        acc += p0 + p1;
       }
-      for (; i <= iend; i++) acc += ld[ea[i]] * s[in + i];
       s[out + a] = dmode == 1 ? acc * s[L.dinv + a] : (dmode == 2 ? acc / s[L.dinv + a] : acc);
     }
     VNL_SYNC();
