@@ -561,12 +561,14 @@ struct EnvWave {
             f = ld6(F + 6 * i);
           }
           const int j = anc_of(e);
-          vreal v = dot(f, ld6(L.cdof + 6 * j));
-          if (j == i) v += m.dof_armature[i] + diag_scale * m.dof_damping[i];
-          s[L.LD + e] = v;
+          s[L.LD + e] = dot(f, ld6(L.cdof + 6 * j));
         }
       }
     }
+    VNL_SYNC();
+    // armature and (Euler step) h * damping on the diagonals, one lane per dof: inside the entry loop these two table
+    // reads were an L2 round trip in the middle of a serial chain
+    VNL_FOR(i, m.nv) s[L.LD + madr(i)] += m.dof_armature[i] + diag_scale * m.dof_damping[i];
     VNL_SYNC();
     VNL_PROF(6);
   }
