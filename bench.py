@@ -35,9 +35,9 @@ ENVS_PER_GPU = 4096
 B_ALG = 6284.0
 F_ALG = 3.9e6 - 0.68e6  # step kernel only (the policy forward is a separate kernel)
 # HBM bytes per step-kernel launch from the PMC counters (profiles/r01f_full_path_summary.md: separate
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command, 4096 envs): 11,220 KB fetched
-# (x2 gfx950 read correction = 22.4 MB, an upper bound for 4-B/lane accesses) + 32.0 MB written.
-TRAFFIC_PMC_BYTES_4096 = 22.4e6 + 32.0e6
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command, 4096 envs): 11,244 KB fetched
+# (x2 gfx950 read correction = 22.5 MB, an upper bound for 4-B/lane accesses) + 32.0 MB written.
+TRAFFIC_PMC_BYTES_4096 = 22.5e6 + 32.0e6
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 
