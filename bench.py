@@ -10,9 +10,13 @@ Weights are freshly initialised (no checkpoints offline); the state lives in HBM
 protocol of the reference's notebooks/test_rodent.ipynb) and skips the Transition logging.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus 8 ...      # starts the 8 ranks itself (torch.distributed.run) before touching a GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  Besides the contract's keys the line carries
+`free_running`: the same measurement with the auto-reset wrapper off (with the reference's C.20 wrapper bug every
+env of the default workload is reset to its cached first state at every step after the tenth, so the default
+figure re-steps that first state; the free-running figure lets the envs evolve).
 """
 from __future__ import annotations
 
@@ -26,25 +30,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 ENVS_PER_GPU = 4096
-# algorithmic HBM bytes per env-step of the rollout (state in/out, action,
-# obs, traj, reward/done/metrics/info), and tree-sparse algorithmic flops per env-step.
+# algorithmic HBM bytes per env-step of the rollout (state in/out, action, obs, traj,
+# reward/done/metrics/info), and the survey's tree-sparse flop estimate per env-step of the step kernel (worst
+# case: every CG / line-search iteration runs; an estimate, not a count of executed instructions).
 B_ALG = 6284.0
 F_ALG = 3.9e6 - 0.68e6  # step kernel only (the policy forward is a separate kernel)
-# HBM bytes per step-kernel launch from the PMC counters (profiles/r01f_full_path_summary.md: separate
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command, 4096 envs): 11,244 KB fetched
-# (x2 gfx950 read correction = 22.5 MB, an upper bound for 4-B/lane accesses) + 32.0 MB written.
-TRAFFIC_PMC_BYTES_4096 = 22.5e6 + 32.0e6
+# HBM bytes per step-kernel launch cannot be measured from inside this script (PMC counters need rocprofv3):
+# `roofline.traffic` is read from profiles/traffic_latest.json, written by tools/pmc_traffic.py from separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (the file names its source);
+# null when that file is absent or was taken at another env count.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_latest.json")
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--clips", type=int, default=1, help="number of resident reference clips (synthesised from the "
+                    "groom clip when > 1: SURVEY 8(d) config 4), random clip per env")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autoreset", action="store_true", help="main measurement without the auto-reset wrapper")
+    ap.add_argument("--no-free-running", action="store_true", help="skip the additional free-running measurement")
+    ap.add_argument("--random-actions", action="store_true")
+    return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`--gpus N` outside a torchrun launch: start the N ranks as children of torch.distributed.run.  This parent
+    has not imported torch and never touches the GPU; rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(env, num_envs: int, max_steps: int = 200, budget_s: float = 12.0, seed: int = 1) -> dict:
     """Time the CPU oracle (float32 build, OpenMP over envs) on a bounded sample of the same workload: control
     steps of `num_envs` envs until `budget_s` seconds of CPU work are spent (at most `max_steps`)."""
+    import numpy as np
+
     import helpers as H
 
     o = H.make_oracle(env, "f32")
@@ -69,20 +105,18 @@ def cpu_baseline(env, num_envs: int, max_steps: int = 200, budget_s: float = 12.
 
 
 def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-autoreset", action="store_true")
-    ap.add_argument("--random-actions", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    dist = None
     if distributed:
         import torch.distributed as dist
 
@@ -98,23 +132,15 @@ def main() -> None:
     from vnl_brax_imitation_amd.envs.wrappers import AutoResetWrapper, EpisodeWrapper
 
     B = args.envs_per_gpu
-    base = RodentTracking(H.reference_clip(), num_envs=B, device=dev, **H.env_kwargs())
-    env = base if args.no_autoreset else AutoResetWrapper(EpisodeWrapper(base, episode_length=150, action_repeat=1))
-    gen = torch.Generator(device="cpu")
-    gen.manual_seed(1234 + rank)  # independent stream per rank: envs shard, nothing crosses the links
-    state = env.reset(gen)
-    total = args.steps + args.warmup
-    unroll = 20
-    if args.random_actions:
-        actions = torch.clamp(0.3 * torch.randn((total, B, 30), generator=gen), -1.0, 1.0).to(dev)
+    clip = H.reference_clip()
+    if args.clips > 1:
+        from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
 
-        def run(k0, n, timed):
-            nonlocal state
-            for k in range(n):
-                if timed:
-                    base.kernel_events = ev[k]
-                state = env.step(state, actions[k0 + k])
-    else:
+        clip = pp.synthesize_clips(H.model(), H.golden_qpos(), args.clips, seed=0)
+    base = RodentTracking(clip, num_envs=B, device=dev, **H.env_kwargs())
+    unroll = 20
+    policy = gdev = acting = None
+    if not args.random_actions:
         from vnl_brax_imitation_amd import configs
         from vnl_brax_imitation_amd.ppo_imitation import acting, ppo_networks, running_statistics
 
@@ -129,60 +155,92 @@ def main() -> None:
         assert policy.__name__ == "policy_hip"
         gdev = torch.Generator(device=dev).manual_seed(99 + rank)
 
-        class _Timed:  # records the (start, end) events of every step-kernel launch of the timed region
-            def __init__(self):
-                self.k = 0
-
-        tm = _Timed()
+    def measure(autoreset: bool, steps: int, warmup: int) -> dict:
+        """W untimed + K timed steps of the hot path, barrier + synchronize on both sides, MAX over ranks; the step
+        kernel's own duration from HIP events recorded around its launch on the launch stream."""
+        env = AutoResetWrapper(EpisodeWrapper(base, episode_length=150, action_repeat=1)) if autoreset else base
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(1234 + rank)  # independent stream per rank: envs shard, nothing crosses the links
+        state = env.reset(gen)
+        ev = []
         orig_step = base.step
+        k_ev = [None]
 
         def step_hook(st_, a_):
-            if tm.k is not None and tm.k < len(ev):
-                base.kernel_events = ev[tm.k]
-                tm.k += 1
+            if k_ev[0] is not None and k_ev[0] < len(ev):
+                base.kernel_events = ev[k_ev[0]]
+                k_ev[0] += 1
             return orig_step(st_, a_)
 
-        extra = ("traj",) if args.no_autoreset else ("truncation", "traj")  # truncation comes from EpisodeWrapper
+        if args.random_actions:
+            actions = torch.clamp(0.3 * torch.randn((steps + warmup, B, 30), generator=gen), -1.0, 1.0).to(dev)
 
-        def run(k0, n, timed):
-            nonlocal state
-            tm.k = 0 if timed else None
-            base.step = step_hook if timed else orig_step
-            done = 0
-            while done < n:
-                chunk = min(unroll, n - done)
-                state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=extra)
-                done += chunk
-            base.step = orig_step
-    torch.cuda.synchronize(dev)
+            def run(k0, n, timed):
+                nonlocal state
+                k_ev[0] = 0 if timed else None
+                base.step = step_hook if timed else orig_step
+                for k in range(n):
+                    state = env.step(state, actions[k0 + k])
+                base.step = orig_step
+        else:
+            extra = ("truncation", "traj") if autoreset else ("traj",)  # truncation comes from EpisodeWrapper
 
-    ev = []
-    run(0, args.warmup, False)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    base.kernel_events = None
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
+            def run(k0, n, timed):
+                nonlocal state
+                k_ev[0] = 0 if timed else None
+                base.step = step_hook if timed else orig_step
+                done = 0
+                while done < n:
+                    chunk = min(unroll, n - done)
+                    state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=extra)
+                    done += chunk
+                base.step = orig_step
+
         torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps, True)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
+        run(0, warmup, False)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        base.kernel_events = None
         torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    base.kernel_events = None
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    finite = bool(torch.isfinite(state.obs).all().item())
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(warmup, steps, True)
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        base.kernel_events = None
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return dict(dt=dt, kernel_ms=kernel_ms, finite=bool(torch.isfinite(state.obs).all().item()),
+                    done_frac=float(state.done.float().mean().item()))
+
+    main_m = measure(not args.no_autoreset, args.steps, args.warmup)
+    free_m = None
+    if not args.no_free_running and not args.no_autoreset:
+        free_m = measure(False, args.steps, args.warmup)
 
     if rank == 0:
+        dt, kernel_ms = main_m["dt"], main_m["kernel_ms"]
         value = world * B * args.steps / dt
         per_gpu_kernel_rate = B / (kernel_ms * 1e-3)
-        achieved_gbs = B_ALG * B / (kernel_ms * 1e-3) / 1e9
+        hbm_gbs = B_ALG * B / (kernel_ms * 1e-3) / 1e9
+        valu_tflops = per_gpu_kernel_rate * F_ALG / 1e12
+        traffic, traffic_src = None, None
+        if os.path.exists(TRAFFIC_FILE):
+            tf = json.load(open(TRAFFIC_FILE))
+            if int(tf.get("envs", 0)) == B:
+                traffic, traffic_src = float(tf["bytes_per_launch"]), tf.get("source")
+        workload = ("rodent imitation rollout, " +
+                    ("single groom clip, " if args.clips == 1 else f"{args.clips} synthesised clips (random clip per env), ") +
+                    f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else "intention-policy forward (HIP) -> ") +
+                    "RodentTracking.step (5 substeps, CG 6/6) -> " + f"auto-reset {'off' if args.no_autoreset else 'on'}" +
+                    ("" if args.random_actions else " -> Transition logging (unroll 20)"))
         out = {
             "metric": "env-steps/sec (whole node), rodent imitation, num_envs=4096/GPU",
             "value": value,
@@ -199,39 +257,43 @@ def main() -> None:
                                       "freshly initialised intention network (seed 0)") +
                      "; reference clip = the shipped groom clip re-processed to 66 bodies; model = compiled rodent.xml "
                      "(scale 0.9); start frames / reset noise from torch Philox"),
-            "config": {
-                "workload": "rodent imitation rollout, single groom clip, "
-                            f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else
-                                                 "intention-policy forward (HIP) -> ") +
-                            "RodentTracking.step (5 substeps, CG 6/6) -> " +
-                            f"auto-reset {'off' if args.no_autoreset else 'on'}" +
-                            ("" if args.random_actions else " -> Transition logging (unroll 20)"),
-                "envs_per_gpu": B,
-                "parallelism": f"env-sharded x{world}, no data-path collective",
-            },
+            "config": {"workload": workload, "envs_per_gpu": B, "clips": args.clips,
+                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+            # The fused step kernel is bound by the FP32 vector ALU / dependent on-chip latency, not by HBM or MFMA
+            # (~500 flop per HBM byte), so the roofline is priced against the fp32 VALU peak; the HBM
+            # figures (what north_star asks to see) are kept beside it.
             "roofline": {
-                "bound": "hbm",
+                "bound": "valu",
                 "kernel": "vnl_step_kernel",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": TRAFFIC_PMC_BYTES_4096 if B == 4096 else None,
+                "achieved": valu_tflops,
+                "peak": VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": valu_tflops / VALU_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": F_ALG * B,
+                "algorithmic_flops_note": "SURVEY 8(d) tree-sparse estimate, worst-case iteration counts",
                 "algorithmic_bytes_per_launch": B_ALG * B,
-                "note": "the fused step is FP32-VALU/latency bound, not HBM bound (SURVEY 8d); valu_frac is the "
-                        "honest figure",
-                "valu_achieved_tflops": per_gpu_kernel_rate * F_ALG / 1e12,
-                "valu_peak_tflops": VALU_PEAK_TFLOPS,
-                "valu_frac": per_gpu_kernel_rate * F_ALG / 1e12 / VALU_PEAK_TFLOPS,
+                "hbm_achieved_gbs": hbm_gbs,
+                "hbm_peak_gbs": HBM_PEAK_GBS,
+                "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
             },
-            "finite": finite,
+            "finite": main_m["finite"],
+            "done_frac_last_step": main_m["done_frac"],
         }
+        if free_m is not None:
+            out["free_running"] = {
+                "value": world * B * args.steps / free_m["dt"], "unit": "env-steps/s",
+                "ms_per_step": free_m["dt"] / args.steps * 1e3, "kernel_ms": free_m["kernel_ms"],
+                "finite": free_m["finite"], "done_frac_last_step": free_m["done_frac"],
+                "note": "same hot path with the auto-reset wrapper off: envs evolve freely for warmup + steps control steps",
+            }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(base, num_envs=1024)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -141,9 +141,14 @@ int vnl_env_reset(vnl_env*, const int32_t* start_frame, const float* noise, cons
 int vnl_env_step(vnl_env*, const float* action, const vnl_state* state, void* stream);
 
 /* Bisection hooks.  The per-env working set lives in LDS; with debug on, every reset/step
- * also copies it to a device dump [num_envs][row_stride].  vnl_env_scratch returns the device
+ * also copies it to a device dump [num_envs][row_stride]: enable = 1 at the end of the kernel,
+ * enable = 2 (step only) as the LAST forward pass of the step leaves it, i.e. before the Euler
+ * update reuses the space of the constraint rows; 0 = off.  vnl_env_scratch returns the device
  * pointer of a named section inside row 0 ("qLD", "qfrc_smooth", "qacc_smooth", "qacc",
- * "efc_D", "efc_aref", "con_dist", ...) and its element count; env e is at +e*row_stride. */
+ * "efc_D", "Jaref", "qfrc_constraint", ...) and its element count; env e is at +e*row_stride.
+ * The section "solver_trace" is separate from the image: int32 [num_envs][n_frames][264], the
+ * discrete decisions (warm start, iteration counts, line-search bracket decisions, active-row
+ * counts) of the solver call of every substep, layout in csrc/vnl_types.h (VNL_TRACE_*). */
 int vnl_env_debug(vnl_env*, int32_t enable, int32_t* row_stride);
 int vnl_env_scratch(const vnl_env*, const char* name, float** dev_ptr, int32_t* count);
 

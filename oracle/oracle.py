@@ -99,6 +99,17 @@ class Oracle:
                                     C.c_void_p, C.POINTER(_State)]
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
                                    C.POINTER(_State)]
+        L.orc_env_step_trace.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
+                                         C.POINTER(_State), C.c_void_p]
+        L.orc_env_step_follow.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
+                                          C.POINTER(_State), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_env_glue.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.POINTER(_State)]
+        L.orc_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.orc_get_option.argtypes = [C.c_char_p]
+        L.orc_solver_trace.restype = C.POINTER(C.c_int)
+        L.orc_solver_trace.argtypes = [C.c_void_p]
+        self.trace_ints = L.orc_trace_ints()
         assert L.orc_envspec_size() == C.sizeof(EnvSpec)
         self._blob = C.create_string_buffer(blob, len(blob))
         h = C.c_void_p()
@@ -126,6 +137,25 @@ class Oracle:
     @property
     def solver_niter(self) -> int:
         return self.lib.orc_solver_niter(self.data)
+
+    @property
+    def solver_trace(self) -> np.ndarray:
+        """Discrete decisions of the last single-env solve (layout: vnl_oracle.c, ORC_TRACE_*)."""
+        return np.ctypeslib.as_array(self.lib.orc_solver_trace(self.data), shape=(self.trace_ints,)).copy()
+
+    # ---- Appendix-B switches (process-wide for this library instance) -------
+    OPTIONS = ("quat_writeback", "capsule_frame_axis", "ls_mid_first", "ls_tie_lo", "inactive_pos_zero",
+               "contact_rows_by_type", "reset_warmstart_zero")
+
+    def set_option(self, name: str, value: int) -> None:
+        if self.lib.orc_set_option(name.encode(), int(value)) != 0:
+            raise KeyError(name)
+
+    def get_option(self, name: str) -> int:
+        v = self.lib.orc_get_option(name.encode())
+        if v < 0:
+            raise KeyError(name)
+        return v
 
     # ---- batched env ------------------------------------------------------
     def bind_env(self, spec: dict, clip: dict, nbody: int, nq: int, nv: int, nu: int) -> None:
@@ -166,11 +196,41 @@ class Oracle:
         assert rc == 0
         return st
 
-    def env_step(self, st: dict, action: np.ndarray) -> dict:
-        """In-place on `st` (like the product's step); returns st for convenience."""
+    def env_step(self, st: dict, action: np.ndarray, trace: bool = False):
+        """In-place on `st` (like the product's step); returns st, or (st, trace[B][n_frames][trace_ints])."""
         B = st["qpos"].shape[0]
         a = np.ascontiguousarray(action, dtype=self.real)
         cs = self._cstate(st)
-        rc = self.lib.orc_env_step(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data, C.byref(cs))
+        tr = np.zeros((B, self.spec.n_frames, self.trace_ints), dtype=np.int32) if trace else None
+        rc = self.lib.orc_env_step_trace(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data,
+                                         C.byref(cs), tr.ctypes.data if trace else None)
+        assert rc == 0
+        return (st, tr) if trace else st
+
+    def env_step_follow(self, st: dict, action: np.ndarray, follow: np.ndarray):
+        """env_step whose solver takes its discrete decisions from `follow` ([B][n_frames][trace_ints] int32, another
+        implementation's trace) instead of its own comparisons.  Returns (st, trace, report[B][n_frames][8]); the
+        report says whether the followed decisions were legitimate (layout: vnl_oracle.c, ORC_FOLLOW_REPORT)."""
+        B = st["qpos"].shape[0]
+        a = np.ascontiguousarray(action, dtype=self.real)
+        f = np.ascontiguousarray(follow, dtype=np.int32).reshape(B, self.spec.n_frames, self.trace_ints)
+        cs = self._cstate(st)
+        tr = np.zeros((B, self.spec.n_frames, self.trace_ints), dtype=np.int32)
+        rep = np.zeros((B, self.spec.n_frames, 8), dtype=self.real)
+        rc = self.lib.orc_env_step_follow(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data,
+                                          C.byref(cs), tr.ctypes.data, f.ctypes.data, rep.ctypes.data)
+        assert rc == 0
+        return st, tr, rep
+
+    def env_glue(self, st: dict, old_qpos: np.ndarray, old_xpos: np.ndarray) -> dict:
+        """rodent.py:183-239 on a caller-supplied NEW pipeline state: `st` holds the new qpos / qvel / act /
+        qacc_warmstart / xpos / xmat1 / com1 / qfrc_actuator and the OLD frame counters; fills obs / traj / reward /
+        done / metrics / termination_error in place and advances the counters."""
+        B = st["qpos"].shape[0]
+        oq = np.ascontiguousarray(old_qpos, dtype=self.real)
+        ox = np.ascontiguousarray(old_xpos, dtype=self.real).reshape(B, -1)
+        cs = self._cstate(st)
+        rc = self.lib.orc_env_glue(self.model, C.byref(self.spec), C.byref(self._clip), B, oq.ctypes.data,
+                                   ox.ctypes.data, C.byref(cs))
         assert rc == 0
         return st

@@ -20,7 +20,7 @@
  * tree-sparse / matrix-free algorithms, is checked against an independently
  * structured implementation.  What IS pinned by reference data: forward
  * kinematics, subtree COM and the egocentric transform against the shipped
- * clip (tests/golden/groom_clip.npz; see tests/test_oracle_golden.py).
+ * clip (tests/golden/groom_clip.npz; see tests/test_oracle.py and tests/test_model_golden.py).
  *
  * Precision: `real` is double unless -DORC_F32 (then float, as JAX's default).
  *
@@ -56,6 +56,52 @@ typedef double real;
 #define MJ_MINVAL ((real)1e-15)
 #define MJ_MINIMP ((real)0.0001)
 #define MJ_MAXIMP ((real)0.9999)
+
+/*
+ * Named switches for the items of the MJX restatement that are recalled rather than verified
+ * ("least-certain items" 1-5 and 8).  Defaults = the reading the product
+ * implements; tests/test_oracle_switches.py shows which outputs move, and by how much, under each
+ * alternative, so that a later run against real MJX can settle them one at a time.
+ */
+typedef struct {
+  int quat_writeback;       /* B.1 (item 1): kinematics writes the normalised free-joint quaternion back into qpos */
+  int capsule_frame_axis;   /* item 2: plane-capsule tangent = capsule axis projected on the plane (else make_frame(n)) */
+  int ls_mid_first;         /* item 3: line search applies the two midpoint replacement tests before the Newton ones */
+  int ls_tie_lo;            /* item 3: lo.cost == hi.cost picks lo (default: lo.cost < hi.cost ? lo : hi, i.e. hi) */
+  int inactive_pos_zero;    /* item 4: rows masked out by make_constraint report pos = 0 (else they keep their pos) */
+  int contact_rows_by_type; /* item 5: contact rows grouped by collision function (sphere, capsule, ellipsoid) */
+  int reset_warmstart_zero; /* item 8: qacc_warmstart after pipeline_init is zero (else the init solve's qacc) */
+} orc_options;
+static orc_options g_opt = {1, 1, 0, 0, 1, 0, 0};
+int orc_set_option(const char *name, int value) {
+#define OPT(f)                 \
+  if (strcmp(name, #f) == 0) { \
+    g_opt.f = value;           \
+    return 0;                  \
+  }
+  OPT(quat_writeback) OPT(capsule_frame_axis) OPT(ls_mid_first) OPT(ls_tie_lo) OPT(inactive_pos_zero)
+  OPT(contact_rows_by_type) OPT(reset_warmstart_zero)
+#undef OPT
+  return -1;
+}
+int orc_get_option(const char *name) {
+#define OPT(f) \
+  if (strcmp(name, #f) == 0) return g_opt.f;
+  OPT(quat_writeback) OPT(capsule_frame_axis) OPT(ls_mid_first) OPT(ls_tie_lo) OPT(inactive_pos_zero)
+  OPT(contact_rows_by_type) OPT(reset_warmstart_zero)
+#undef OPT
+  return -1;
+}
+
+/* Solver trace: the DISCRETE decisions of one solver.solve call, so that a test can tell "same decisions, same
+ * numbers" from "a decision flipped" (the 6-iteration CG is not converged, so a flipped decision moves the result
+ * by far more than rounding).  Same layout as the product's debug trace (csrc/vnl_body.h, VNL_TRACE_*):
+ * [0] warm start used, [1] iterations, then per iteration 32 ints: [0] float32 bits of the accepted step length,
+ * [1] line-search iterations, [2] the four replacement decisions of every line-search iteration (4 bits each),
+ * [3] pick (0 none, 1 lo, 2 hi), [4..24) rows active at every trial step length (p0, first Newton point, then
+ * lo_next / hi_next / mid per line-search iteration). */
+#define ORC_TRACE_ITERS 8
+#define ORC_TRACE_INTS (8 + 32 * ORC_TRACE_ITERS)
 
 #define JNT_FREE 0
 #define JNT_HINGE 3
@@ -223,6 +269,10 @@ typedef struct orc_data {
   /* actuation / acceleration */
   real *act_dot, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc, *qfrc_constraint;
   int solver_niter;
+  int trace[ORC_TRACE_INTS]; /* discrete decisions of the last solve (layout above) */
+  int *row_live;             /* nefc: row not masked out by make_constraint */
+  const int *follow;         /* NULL, or a trace whose decisions the next solve takes instead of its own */
+  real follow_report[8];     /* legitimacy of the followed decisions (see slv section) */
   /* scratch */
   real *w0, *w1, *w2, *w3, *w4, *w5, *wefc0, *wefc1, *quad;
   real *arena;
@@ -266,10 +316,12 @@ orc_data *orc_data_create(const orc_model *m) {
   d->w5 = ralloc(6 * nb + 6 * nv);
   d->wefc0 = ralloc(ne), d->wefc1 = ralloc(ne), d->quad = ralloc(3 * (size_t)ne);
 #undef ralloc
+  d->row_live = (int *)calloc(ne ? ne : 1, sizeof(int));
   return d;
 }
 
 void orc_data_destroy(orc_data *d) {
+  free(d->row_live);
   free(d->arena);
   free(d);
 }
@@ -295,6 +347,8 @@ int orc_data_field(const orc_model *m, orc_data *d, const char *name, real **ptr
 }
 int orc_real_size(void) { return (int)sizeof(real); }
 int orc_solver_niter(const orc_data *d) { return d->solver_niter; }
+const int *orc_solver_trace(const orc_data *d) { return d->trace; }
+int orc_trace_ints(void) { return ORC_TRACE_INTS; }
 
 /* ------------------------------------------------------------------------- */
 /* math [UPSTREAM mjx/_src/math.py]                                          */
@@ -398,7 +452,8 @@ void orc_kinematics(const orc_model *m, orc_data *d) {
         axis[0] = 0, axis[1] = 0, axis[2] = 1;
         for (int i = 0; i < 4; i++) quat[i] = d->qpos[qa + 3 + i];
         normalize4(quat);
-        for (int i = 0; i < 4; i++) d->qpos[qa + 3 + i] = quat[i]; /* normalised quat written back */
+        if (g_opt.quat_writeback)
+          for (int i = 0; i < 4; i++) d->qpos[qa + 3 + i] = quat[i]; /* normalised quat written back */
       } else {
         real qloc[4], q2[4];
         rotate(tmp, m->jnt_pos + 3 * j, quat);
@@ -587,6 +642,7 @@ void orc_collision(const orc_model *m, orc_data *d) {
       real frame[9];
       memcpy(frame, n, 3 * sizeof(real)), memcpy(frame + 3, bvec, 3 * sizeof(real));
       cross3(frame + 6, n, bvec);
+      if (!g_opt.capsule_frame_axis) make_frame(frame, n);
       for (int s = 0; s < 2; s++) {
         real sgn = s == 0 ? 1 : -1, c[3], rel[3];
         for (int i = 0; i < 3; i++) c[i] = gpos[i] + sgn * axis[i] * size[1], rel[i] = c[i] - pp[i];
@@ -642,13 +698,26 @@ void orc_make_constraint(const orc_model *m, orc_data *d) {
     real pos = (dmin < dmax ? dmin : dmax) - m->jnt_margin[j];
     int active = pos < 0;
     d->efc_J[r * nv + da] = active ? (dmin < dmax ? (real)1 : (real)-1) : 0;
-    d->efc_pos[r] = active ? pos : 0;
+    d->row_live[r] = active;
+    d->efc_pos[r] = (active || !g_opt.inactive_pos_zero) ? pos : 0;
     invweight[r] = m->dof_invweight0[da];
     memcpy(solref + 2 * r, m->jnt_solref + 2 * j, 2 * sizeof(real));
     memcpy(solimp + 5 * r, m->jnt_solimp + 5 * j, 5 * sizeof(real));
   }
   real *jac = (real *)malloc(sizeof(real) * 3 * nv);
-  for (int g = 0; g < m->ncg; g++) {
+  int *gorder = (int *)malloc(sizeof(int) * (m->ncg + 1));
+  {
+    int k = 0;
+    if (g_opt.contact_rows_by_type) {
+      for (int ty = 0; ty < 8; ty++)
+        for (int g = 0; g < m->ncg; g++)
+          if (m->cg_type[g] == ty) gorder[k++] = g;
+    } else {
+      for (int g = 0; g < m->ncg; g++) gorder[k++] = g;
+    }
+  }
+  for (int gi = 0; gi < m->ncg; gi++) {
+    int g = gorder[gi];
     int b = m->cg_bodyid[g];
     real mu[2] = {m->cg_friction[3 * g], m->cg_friction[3 * g]}; /* contact friction[:2] = (slide, slide) */
     real t = m->body_invweight0[0] + m->body_invweight0[2 * b];
@@ -666,14 +735,15 @@ void orc_make_constraint(const orc_model *m, orc_data *d) {
               real jn = dot3(fr, jac + 3 * dd), jt = dot3(fr + 3 * (1 + t2), jac + 3 * dd);
               d->efc_J[r * nv + dd] = jn + jt * f;
             }
-          d->efc_pos[r] = active ? dist : 0;
+          d->efc_pos[r] = (active || !g_opt.inactive_pos_zero) ? dist : 0;
+          d->row_live[r] = active;
           invweight[r] = (t + f * f * t) * 2 * f * f / m->impratio;
           memcpy(solref + 2 * r, m->cg_solref + 2 * g, 2 * sizeof(real));
           memcpy(solimp + 5 * r, m->cg_solimp + 5 * g, 5 * sizeof(real));
         }
     }
   }
-  free(jac);
+  free(jac), free(gorder);
   for (r = 0; r < ne; r++) {
     real timeconst = solref[2 * r], dampratio = solref[2 * r + 1];
     real dmin = solimp[5 * r], dmax = solimp[5 * r + 1], width = solimp[5 * r + 2], mid = solimp[5 * r + 3],
@@ -850,12 +920,41 @@ typedef struct {
   real alpha, cost, deriv_0, deriv_1;
 } ls_point;
 
-static ls_point ls_eval(const orc_model *m, const slv_ctx *c, const real *jv, const real *quad, const real *quad_gauss,
-                        real alpha) {
+/* Decision FOLLOWING (test instrument).  When d->follow points at a trace recorded by another implementation of
+ * this solver (the product's debug trace, same layout as d->trace), every discrete decision -- warm start, number of
+ * CG iterations, initial bracket order, number of line-search iterations, the four bracket replacements of each,
+ * the final pick -- is taken from that trace instead of from the oracle's own comparisons, so that the oracle
+ * evaluates the SAME branch of the algorithm and its float64 numbers can be compared with the other side's float32
+ * numbers at rounding level.  Whether the followed decisions were legitimate is judged separately and reported in
+ * d->follow_report:
+ *   [0] worst line search: (cost(alpha followed) - cost(alpha natural)) / (|q0| + |alpha q1| + |alpha^2 q2|), where
+ *       "natural" is this oracle's own float64 line search from the same state: > ~1e-6 means the followed step was
+ *       worse than rounding can explain;
+ *   [1] worst CG-exit disagreement: distance of the natural exit test from its threshold, in units of the float32
+ *       rounding of the costs, 0 if the exit iteration agreed;
+ *   [2] warm-start disagreement: |cost_warm - cost_smooth| / (|cost_warm| + |cost_smooth|), 0 if the choice agreed;
+ *   [3] number of trial step lengths at which the set of active rows had a different size;
+ *   [4] the largest, over those, of min_r |Jaref_r + alpha jv_r| / (|Jaref_r| + |alpha jv_r|): how far from its
+ *       switching point the nearest row was (rounding-sized: a row sat on its kink);
+ *   [5] number of followed decisions that differ from the natural ones. */
+#define ORC_FOLLOW_REPORT 8
+
+static ls_point ls_eval(const orc_model *m, const orc_data *d, const slv_ctx *c, const real *jv, const real *quad,
+                        const real *quad_gauss, real alpha, int *nactive, real *kink) {
   real q0 = quad_gauss[0], q1 = quad_gauss[1], q2 = quad_gauss[2];
+  int na = 0;
+  real near = 1;
   for (int r = 0; r < m->nefc; r++) {
-    if (c->Jaref[r] + alpha * jv[r] < 0) q0 += quad[3 * r], q1 += quad[3 * r + 1], q2 += quad[3 * r + 2];
+    real x = c->Jaref[r] + alpha * jv[r];
+    if (x < 0) q0 += quad[3 * r], q1 += quad[3 * r + 1], q2 += quad[3 * r + 2];
+    if ((nactive || kink) && d->row_live[r]) { /* rows make_constraint did not mask out */
+      if (x < 0) na++;
+      real den = RFABS(c->Jaref[r]) + RFABS(alpha * jv[r]);
+      if (den > 0 && RFABS(x) / den < near) near = RFABS(x) / den;
+    }
   }
+  if (nactive) *nactive = na;
+  if (kink) *kink = near;
   ls_point p;
   p.alpha = alpha;
   p.cost = alpha * alpha * q2 + alpha * q1 + q0;
@@ -864,7 +963,116 @@ static ls_point ls_eval(const orc_model *m, const slv_ctx *c, const real *jv, co
   return p;
 }
 
-static void slv_linesearch(const orc_model *m, orc_data *d, slv_ctx *c) {
+/* one exact line search from the current solver state; tr: trace record of this iteration to fill (or NULL);
+ * fol: record to follow (or NULL).  Returns the accepted step length (0: no improvement). */
+static real ls_run(const orc_model *m, orc_data *d, const slv_ctx *c, const real *jv, const real *quad, const real *qg,
+                   real gtol, int *tr, const int *fol, real *report) {
+  int nev = 0, cnt = 0;
+  real kink = 1;
+#define EVAL(alpha_) ls_eval(m, d, c, jv, quad, qg, (alpha_), &cnt, &kink)
+#define NOTE()                                                         \
+  do {                                                                 \
+    if (tr && nev < 20) tr[4 + nev] = cnt;                             \
+    if (fol && report && nev < 20 && fol[4 + nev] != cnt) {            \
+      report[3] += 1;                                                  \
+      if (kink > report[4]) report[4] = kink;                          \
+    }                                                                  \
+    nev++;                                                             \
+  } while (0)
+  ls_point p0 = EVAL(0);
+  NOTE();
+  ls_point lo = EVAL(p0.alpha - p0.deriv_0 / p0.deriv_1), hi;
+  NOTE();
+  int first_lo = lo.deriv_0 < p0.deriv_0; /* the first Newton point becomes `lo`, p0 becomes `hi` */
+  if (fol) {
+    int f = (fol[2] >> 24) & 1;
+    if (report && f != first_lo) report[5] += 1;
+    first_lo = f;
+  }
+  if (tr) tr[2] |= first_lo << 24;
+  if (first_lo) {
+    hi = p0;
+  } else {
+    hi = lo, lo = p0;
+  }
+  int swap = 1, ls_iter = 0;
+  for (;;) {
+    int done = ls_iter >= m->ls_iterations;
+    done |= !swap;
+    done |= (lo.deriv_0 < 0) && (lo.deriv_0 > -gtol);
+    done |= (hi.deriv_0 > 0) && (hi.deriv_0 < gtol);
+    if (fol) {
+      int fdone = ls_iter >= fol[1];
+      if (report && fdone != done) report[5] += 1;
+      done = fdone;
+    }
+    if (done) break;
+    ls_point lo_next = EVAL(lo.alpha - lo.deriv_0 / lo.deriv_1);
+    NOTE();
+    ls_point hi_next = EVAL(hi.alpha - hi.deriv_0 / hi.deriv_1);
+    NOTE();
+    ls_point mid = EVAL((real)0.5 * (lo.alpha + hi.alpha));
+    NOTE();
+    int swap_lo_next = 0, swap_lo_mid = 0, swap_hi_next = 0, swap_hi_mid = 0;
+    if (fol) {
+      int bits = (fol[2] >> (4 * ls_iter)) & 15;
+      int n1 = (lo.deriv_0 > 0) || (lo.deriv_0 < lo_next.deriv_0);
+      swap_lo_next = bits & 1;
+      if (swap_lo_next) lo = lo_next;
+      int n2 = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
+      swap_lo_mid = (bits >> 1) & 1;
+      if (swap_lo_mid) lo = mid;
+      int n3 = (hi.deriv_0 < 0) || (hi.deriv_0 > hi_next.deriv_0);
+      swap_hi_next = (bits >> 2) & 1;
+      if (swap_hi_next) hi = hi_next;
+      int n4 = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
+      swap_hi_mid = (bits >> 3) & 1;
+      if (swap_hi_mid) hi = mid;
+      if (report) report[5] += (n1 != swap_lo_next) + (n2 != swap_lo_mid) + (n3 != swap_hi_next) + (n4 != swap_hi_mid);
+    } else {
+      if (g_opt.ls_mid_first) { /* alternative order of the replacement tests (Appendix B item 3) */
+        swap_lo_mid = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
+        if (swap_lo_mid) lo = mid;
+        swap_hi_mid = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
+        if (swap_hi_mid) hi = mid;
+      }
+      swap_lo_next = (lo.deriv_0 > 0) || (lo.deriv_0 < lo_next.deriv_0);
+      if (swap_lo_next) lo = lo_next;
+      if (!g_opt.ls_mid_first) {
+        swap_lo_mid = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
+        if (swap_lo_mid) lo = mid;
+      }
+      swap_hi_next = (hi.deriv_0 < 0) || (hi.deriv_0 > hi_next.deriv_0);
+      if (swap_hi_next) hi = hi_next;
+      if (!g_opt.ls_mid_first) {
+        swap_hi_mid = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
+        if (swap_hi_mid) hi = mid;
+      }
+    }
+    swap = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
+    if (tr && ls_iter < 6) tr[2] |= (swap_lo_next | swap_lo_mid << 1 | swap_hi_next << 2 | swap_hi_mid << 3) << (4 * ls_iter);
+    ls_iter++;
+  }
+#undef EVAL
+#undef NOTE
+  int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+  int pick_lo = g_opt.ls_tie_lo ? lo.cost <= hi.cost : lo.cost < hi.cost;
+  int pick = improved ? (pick_lo ? 1 : 2) : 0;
+  if (fol) {
+    if (report && fol[3] != pick) report[5] += 1;
+    pick = fol[3];
+  }
+  real alpha = pick == 0 ? 0 : (pick == 1 ? lo.alpha : hi.alpha);
+  if (tr) {
+    float a32 = (float)alpha;
+    memcpy(&tr[0], &a32, 4);
+    tr[1] = ls_iter, tr[3] = pick;
+  }
+  return alpha;
+}
+
+static void slv_linesearch(const orc_model *m, orc_data *d, slv_ctx *c, int *tr /* 32 ints of this iteration */,
+                           const int *fol, real *report) {
   int nv = m->nv, ne = m->nefc;
   real *mv = d->w0, *jv = d->wefc1, *quad = d->quad;
   real snorm = 0;
@@ -888,37 +1096,18 @@ static void slv_linesearch(const orc_model *m, orc_data *d, slv_ctx *c) {
     quad[3 * r + 1] = jv[r] * c->Jaref[r] * d->efc_D[r];
     quad[3 * r + 2] = (real)0.5 * jv[r] * jv[r] * d->efc_D[r];
   }
-  ls_point p0 = ls_eval(m, c, jv, quad, qg, 0);
-  ls_point lo = ls_eval(m, c, jv, quad, qg, p0.alpha - p0.deriv_0 / p0.deriv_1), hi;
-  if (lo.deriv_0 < p0.deriv_0) {
-    hi = p0;
-  } else {
-    hi = lo, lo = p0;
+  real alpha = ls_run(m, d, c, jv, quad, qg, gtol, tr, fol, report);
+  if (fol && report) { /* how much worse than this oracle's own line search is the followed step? */
+    real a_nat = ls_run(m, d, c, jv, quad, qg, gtol, NULL, NULL, NULL);
+    ls_point pf = ls_eval(m, d, c, jv, quad, qg, alpha, NULL, NULL), pn = ls_eval(m, d, c, jv, quad, qg, a_nat, NULL, NULL);
+    ls_point pz = ls_eval(m, d, c, jv, quad, qg, 0, NULL, NULL);
+    real q1 = pz.deriv_0, q2 = (real)0.5 * pz.deriv_1; /* coefficients at alpha = 0: the scale of the polynomial */
+    real am = RFABS(alpha) > RFABS(a_nat) ? RFABS(alpha) : RFABS(a_nat);
+    real scale = RFABS(pz.cost) + RFABS(am * q1) + RFABS(am * am * q2);
+    real excess = scale > 0 ? (pf.cost - pn.cost) / scale : 0;
+    if (excess > report[0]) report[0] = excess;
   }
-  int swap = 1, ls_iter = 0;
-  for (;;) {
-    int done = ls_iter >= m->ls_iterations;
-    done |= !swap;
-    done |= (lo.deriv_0 < 0) && (lo.deriv_0 > -gtol);
-    done |= (hi.deriv_0 > 0) && (hi.deriv_0 < gtol);
-    if (done) break;
-    ls_point lo_next = ls_eval(m, c, jv, quad, qg, lo.alpha - lo.deriv_0 / lo.deriv_1);
-    ls_point hi_next = ls_eval(m, c, jv, quad, qg, hi.alpha - hi.deriv_0 / hi.deriv_1);
-    ls_point mid = ls_eval(m, c, jv, quad, qg, (real)0.5 * (lo.alpha + hi.alpha));
-    int swap_lo_next = (lo.deriv_0 > 0) || (lo.deriv_0 < lo_next.deriv_0);
-    if (swap_lo_next) lo = lo_next;
-    int swap_lo_mid = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
-    if (swap_lo_mid) lo = mid;
-    int swap_hi_next = (hi.deriv_0 < 0) || (hi.deriv_0 > hi_next.deriv_0);
-    if (swap_hi_next) hi = hi_next;
-    int swap_hi_mid = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
-    if (swap_hi_mid) hi = mid;
-    swap = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
-    ls_iter++;
-  }
-  int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-  real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
-  if (improved) {
+  if (alpha != 0) {
     for (int i = 0; i < nv; i++) c->qacc[i] += c->search[i] * alpha, c->Ma[i] += mv[i] * alpha;
     for (int r = 0; r < ne; r++) c->Jaref[r] += jv[r] * alpha;
   }
@@ -926,6 +1115,9 @@ static void slv_linesearch(const orc_model *m, orc_data *d, slv_ctx *c) {
 
 void orc_solve(const orc_model *m, orc_data *d) {
   int nv = m->nv, ne = m->nefc;
+  const int *fol = d->follow;
+  real *report = fol ? d->follow_report : NULL;
+  if (report) memset(report, 0, sizeof(real) * ORC_FOLLOW_REPORT);
   slv_ctx c;
   c.qacc = ralloc(nv), c.Ma = ralloc(nv), c.Jaref = ralloc(ne), c.grad = ralloc(nv), c.Mgrad = ralloc(nv);
   c.search = ralloc(nv), c.qfrc_constraint = ralloc(nv), c.efc_force = ralloc(ne);
@@ -934,7 +1126,16 @@ void orc_solve(const orc_model *m, orc_data *d) {
   real cost_warm = c.cost;
   slv_init(m, d, &c, d->qacc_smooth);
   real cost_smooth = c.cost;
-  const real *start = cost_warm < cost_smooth ? d->qacc_warmstart : d->qacc_smooth;
+  int use_warm = cost_warm < cost_smooth;
+  if (fol && fol[0] != use_warm) {
+    real den = RFABS(cost_warm) + RFABS(cost_smooth);
+    report[2] = den > 0 ? RFABS(cost_warm - cost_smooth) / den : 0;
+    report[5] += 1;
+    use_warm = fol[0];
+  }
+  const real *start = use_warm ? d->qacc_warmstart : d->qacc_smooth;
+  memset(d->trace, 0, sizeof(d->trace));
+  d->trace[0] = use_warm;
   slv_init(m, d, &c, start);
   slv_update_gradient(m, d, &c);
   for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i];
@@ -949,8 +1150,22 @@ void orc_solve(const orc_model *m, orc_data *d) {
     int done = niter >= m->iterations;
     done |= improvement < m->tolerance;
     done |= gradient < m->tolerance;
+    if (fol) {
+      int fdone = niter >= fol[1];
+      if (fdone != done) {
+        /* distance of the two exit tests from their thresholds, in units of the float32 rounding of their operands */
+        real r_imp = RFABS(c.prev_cost - c.cost - m->tolerance * scale) / ((real)1e-6 * (RFABS(c.prev_cost) + RFABS(c.cost)) + MJ_MINVAL);
+        real r_grd = RFABS(gradient - m->tolerance) / ((real)1e-5 * gradient + MJ_MINVAL);
+        real r = r_imp < r_grd ? r_imp : r_grd;
+        if (!isfinite((double)c.prev_cost)) r = r_grd; /* first pass: prev_cost = inf, only the gradient test can fire */
+        if (r > report[1]) report[1] = r;
+        report[5] += 1;
+      }
+      done = fdone;
+    }
     if (done && !(m->iterations == 1 && niter == 0)) break;
-    slv_linesearch(m, d, &c);
+    slv_linesearch(m, d, &c, niter < ORC_TRACE_ITERS ? d->trace + 8 + 32 * niter : NULL,
+                   (fol && niter < ORC_TRACE_ITERS) ? fol + 8 + 32 * niter : NULL, report);
     memcpy(prev_grad, c.grad, sizeof(real) * nv), memcpy(prev_Mgrad, c.Mgrad, sizeof(real) * nv);
     slv_update_constraint(m, d, &c);
     slv_update_gradient(m, d, &c);
@@ -962,6 +1177,7 @@ void orc_solve(const orc_model *m, orc_data *d) {
     niter++;
   }
   d->solver_niter = niter;
+  d->trace[1] = niter;
   memcpy(d->qacc, c.qacc, sizeof(real) * nv), memcpy(d->qacc_warmstart, c.qacc, sizeof(real) * nv);
   memcpy(d->qfrc_constraint, c.qfrc_constraint, sizeof(real) * nv);
   memcpy(d->efc_force, c.efc_force, sizeof(real) * ne);
@@ -1166,6 +1382,7 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
     memset(d->act, 0, sizeof(real) * m->nu), memset(d->ctrl, 0, sizeof(real) * m->nu);
     memset(d->qacc_warmstart, 0, sizeof(real) * m->nv);
     orc_forward(m, d); /* brax pipeline_init = mjx.forward */
+    if (g_opt.reset_warmstart_zero) memset(d->qacc_warmstart, 0, sizeof(real) * m->nv);
     store_state(m, d, s, i);
     env_traj(m, e, c, d, start_frame[i], traj);
     env_obs(m, e, d, obs);
@@ -1181,10 +1398,81 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
   return 0;
 }
 
-/* rodent.py:178-239 step */
-int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *action,
-                 orc_state *s) {
-  int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
+/* rodent.py:183-239: everything of `step` after pipeline_step.  `d` holds the NEW pipeline state (qpos, qvel, act,
+ * qacc_warmstart and, from its last forward, xpos, xmat[1], subtree_com[1], qfrc_actuator); old_* the state before
+ * the step.  Writes row i of the outputs and advances the frame counters. */
+static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, const orc_data *d, const real *old_qpos,
+                     const real *old_xpos, real *obs, real *traj, orc_state *s, int i) {
+  int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e);
+  int old_frame = s->cur_frame[i], new_frame = old_frame + 1, new_sub = s->sub_clip_frame[i] + 1;
+  env_obs(m, e, d, obs);
+  env_traj(m, e, c, d, new_frame, traj);
+  /* _calculate_reward(state, data): NEW data vs clip row at OLD cur_frame (quirk C.1) */
+  int fo = clampi(old_frame, 0, e->T - 1);
+  real dv[3], acc;
+  for (int k = 0; k < 3; k++)
+    dv[k] = d->subtree_com[3 + k] - (real)c->body_positions[(fo * e->nb + e->com_ref_col) * 3 + k];
+  real rcom = REXP(-100 * norm3(dv));
+  acc = 0;
+  for (int k = 0; k < 3; k++) {
+    real a = d->qvel[k] - (real)c->velocity[fo * 3 + k], b = d->qvel[3 + k] - (real)c->angular_velocity[fo * 3 + k];
+    acc += a * a + b * b;
+  }
+  for (int k = 0; k < nj; k++) {
+    real a = d->qvel[6 + k] - (real)c->joints_velocity[fo * nj + k];
+    acc += a * a;
+  }
+  real rvel = REXP((real)-0.1 * RSQRT(acc));
+  /* rtrunk from the OLD pipeline state and OLD frame (quirk C.2) */
+  real rtrunk = env_termination(m, e, c, old_qpos, old_xpos, old_frame);
+  real qc[4], qr[4], nc = 0, nr = 0, dq = 0;
+  for (int k = 0; k < 4; k++) qc[k] = d->qpos[3 + k], qr[k] = (real)c->quaternion[fo * 4 + k];
+  for (int k = 0; k < 4; k++) nc += qc[k] * qc[k], nr += qr[k] * qr[k];
+  nc = RSQRT(nc), nr = RSQRT(nr);
+  for (int k = 0; k < 4; k++) dq += (qc[k] / nc) * (qr[k] / nr);
+  real dist = 2 * dq * dq - 1;
+  if (dist > 1) dist = 1;
+  real rquat = REXP(-2 * RFABS((real)0.5 * RACOS(dist)));
+  acc = 0;
+  for (int k = 0; k < m->nv; k++) acc += d->qfrc_actuator[k] * d->qfrc_actuator[k];
+  real ract = (real)-0.015 * (acc / m->nv);
+  acc = 0;
+  for (int a = 0; a < e->napp; a++)
+    for (int k = 0; k < 3; k++) {
+      real x = d->xpos[3 * e->app_body[a] + k] - (real)c->body_positions[(fo * e->nb + e->app_ref_col[a]) * 3 + k];
+      acc += x * x;
+    }
+  real rapp = REXP(-400 * RSQRT(acc));
+  real healthy = 1;
+  if (d->qpos[2] < (real)e->healthy_z_lo) healthy = 0;
+  if (d->qpos[2] > (real)e->healthy_z_hi) healthy = 0;
+  rcom *= (real)0.01, rvel *= (real)0.01, rapp *= (real)0.01, rtrunk *= (real)0.01, rquat *= (real)0.01;
+  ract *= (real)0.0001;
+  real total = rcom + rvel + rtrunk + rquat + ract + rapp;
+  real done = rtrunk < 0 ? 1 : 0;
+  if (1 - healthy > done) done = 1 - healthy;
+  real sub_ok = new_sub < e->sub_clip_length ? 1 : 0;
+  if (1 - sub_ok > done) done = 1 - sub_ok;
+  if (isnan(total)) total = 0; /* nan_to_num */
+  if (isinf(total)) total = total > 0 ? (real)3.4028235e38 : (real)-3.4028235e38;
+  for (int k = 0; k < no; k++)
+    if (isnan(obs[k])) obs[k] = 0;
+  if (data_has_nan(m, d)) done = 1;
+  for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (real)obs[k];
+  for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (real)traj[k];
+  s->reward[i] = (real)total, s->done[i] = (real)done;
+  real *mt = s->metrics + (size_t)i * 7;
+  mt[0] = (real)rcom, mt[1] = (real)rvel, mt[2] = (real)rtrunk, mt[3] = (real)rquat, mt[4] = (real)ract;
+  mt[5] = (real)rapp, mt[6] = (real)rtrunk;
+  s->cur_frame[i] = new_frame, s->sub_clip_frame[i] = new_sub;
+  s->termination_error[i] = (real)rtrunk;
+}
+
+/* rodent.py:178-239 step.  trace: NULL or [B][n_frames][ORC_TRACE_INTS], the solver decisions of every substep */
+/* follow / report: NULL, or [B][n_frames][ORC_TRACE_INTS] decisions to follow and [B][n_frames][8] legitimacy report */
+int orc_env_step_follow(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *action,
+                        orc_state *s, int32_t *trace, const int32_t *follow, real *report) {
+  int no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
 #pragma omp parallel
   {
     real *obs = ralloc(no), *traj = ralloc(nt), *old_qpos = ralloc(m->nq), *old_xpos = ralloc(nb3);
@@ -1195,74 +1483,49 @@ int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
       for (int k = 0; k < m->nq; k++) old_qpos[k] = d->qpos[k];
       for (int k = 0; k < nb3; k++) old_xpos[k] = (real)s->xpos[(size_t)i * nb3 + k];
       for (int k = 0; k < m->nu; k++) d->ctrl[k] = (real)action[(size_t)i * m->nu + k];
-      for (int f = 0; f < e->n_frames; f++) orc_step(m, d); /* brax pipeline_step */
-      int old_frame = s->cur_frame[i], new_frame = old_frame + 1, new_sub = s->sub_clip_frame[i] + 1;
-      env_obs(m, e, d, obs);
-      env_traj(m, e, c, d, new_frame, traj);
-      /* _calculate_reward(state, data): NEW data vs clip row at OLD cur_frame (quirk C.1) */
-      int fo = clampi(old_frame, 0, e->T - 1);
-      real dv[3], acc;
-      for (int k = 0; k < 3; k++)
-        dv[k] = d->subtree_com[3 + k] - (real)c->body_positions[(fo * e->nb + e->com_ref_col) * 3 + k];
-      real rcom = REXP(-100 * norm3(dv));
-      acc = 0;
-      for (int k = 0; k < 3; k++) {
-        real a = d->qvel[k] - (real)c->velocity[fo * 3 + k], b = d->qvel[3 + k] - (real)c->angular_velocity[fo * 3 + k];
-        acc += a * a + b * b;
+      for (int f = 0; f < e->n_frames; f++) { /* brax pipeline_step */
+        d->follow = follow ? (const int *)follow + ((size_t)i * e->n_frames + f) * ORC_TRACE_INTS : NULL;
+        orc_step(m, d);
+        d->follow = NULL;
+        if (trace) memcpy(trace + ((size_t)i * e->n_frames + f) * ORC_TRACE_INTS, d->trace, sizeof(d->trace));
+        if (report && follow)
+          memcpy(report + ((size_t)i * e->n_frames + f) * ORC_FOLLOW_REPORT, d->follow_report, sizeof(d->follow_report));
       }
-      for (int k = 0; k < nj; k++) {
-        real a = d->qvel[6 + k] - (real)c->joints_velocity[fo * nj + k];
-        acc += a * a;
-      }
-      real rvel = REXP((real)-0.1 * RSQRT(acc));
-      /* rtrunk from the OLD pipeline state and OLD frame (quirk C.2) */
-      real rtrunk = env_termination(m, e, c, old_qpos, old_xpos, old_frame);
-      real qc[4], qr[4], nc = 0, nr = 0, dq = 0;
-      for (int k = 0; k < 4; k++) qc[k] = d->qpos[3 + k], qr[k] = (real)c->quaternion[fo * 4 + k];
-      for (int k = 0; k < 4; k++) nc += qc[k] * qc[k], nr += qr[k] * qr[k];
-      nc = RSQRT(nc), nr = RSQRT(nr);
-      for (int k = 0; k < 4; k++) dq += (qc[k] / nc) * (qr[k] / nr);
-      real dist = 2 * dq * dq - 1;
-      if (dist > 1) dist = 1;
-      real rquat = REXP(-2 * RFABS((real)0.5 * RACOS(dist)));
-      acc = 0;
-      for (int k = 0; k < m->nv; k++) acc += d->qfrc_actuator[k] * d->qfrc_actuator[k];
-      real ract = (real)-0.015 * (acc / m->nv);
-      acc = 0;
-      for (int a = 0; a < e->napp; a++)
-        for (int k = 0; k < 3; k++) {
-          real x = d->xpos[3 * e->app_body[a] + k] - (real)c->body_positions[(fo * e->nb + e->app_ref_col[a]) * 3 + k];
-          acc += x * x;
-        }
-      real rapp = REXP(-400 * RSQRT(acc));
-      real healthy = 1;
-      if (d->qpos[2] < (real)e->healthy_z_lo) healthy = 0;
-      if (d->qpos[2] > (real)e->healthy_z_hi) healthy = 0;
-      rcom *= (real)0.01, rvel *= (real)0.01, rapp *= (real)0.01, rtrunk *= (real)0.01, rquat *= (real)0.01;
-      ract *= (real)0.0001;
-      real total = rcom + rvel + rtrunk + rquat + ract + rapp;
-      real done = rtrunk < 0 ? 1 : 0;
-      if (1 - healthy > done) done = 1 - healthy;
-      real sub_ok = new_sub < e->sub_clip_length ? 1 : 0;
-      if (1 - sub_ok > done) done = 1 - sub_ok;
-      if (isnan(total)) total = 0; /* nan_to_num */
-      if (isinf(total)) total = total > 0 ? (real)3.4028235e38 : (real)-3.4028235e38;
-      for (int k = 0; k < no; k++)
-        if (isnan(obs[k])) obs[k] = 0;
-      if (data_has_nan(m, d)) done = 1;
       store_state(m, d, s, i);
-      for (int k = 0; k < no; k++) s->obs[(size_t)i * no + k] = (real)obs[k];
-      for (int k = 0; k < nt; k++) s->traj[(size_t)i * nt + k] = (real)traj[k];
-      s->reward[i] = (real)total, s->done[i] = (real)done;
-      real *mt = s->metrics + (size_t)i * 7;
-      mt[0] = (real)rcom, mt[1] = (real)rvel, mt[2] = (real)rtrunk, mt[3] = (real)rquat, mt[4] = (real)ract;
-      mt[5] = (real)rapp, mt[6] = (real)rtrunk;
-      s->cur_frame[i] = new_frame, s->sub_clip_frame[i] = new_sub;
-      s->termination_error[i] = (real)rtrunk;
+      env_glue(m, e, c, d, old_qpos, old_xpos, obs, traj, s, i);
     }
     orc_data_destroy(d);
     free(obs), free(traj), free(old_qpos), free(old_xpos);
   }
+  return 0;
+}
+int orc_env_step_trace(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *action,
+                       orc_state *s, int32_t *trace) {
+  return orc_env_step_follow(m, e, c, B, action, s, trace, NULL, NULL);
+}
+int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *action, orc_state *s) {
+  return orc_env_step_follow(m, e, c, B, action, s, NULL, NULL, NULL);
+}
+
+/* The glue alone, on a pipeline state supplied by the caller (the product's own post-step state): `s` holds the
+ * NEW qpos / qvel / act / qacc_warmstart / xpos / xmat1 / com1 / qfrc_actuator and the OLD frame counters; old_qpos
+ * [B][nq], old_xpos [B][3 nbody] the state before the step.  Fills obs / traj / reward / done / metrics /
+ * termination_error and advances the counters, exactly as orc_env_step does after its substeps. */
+int orc_env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *old_qpos,
+                 const real *old_xpos, orc_state *s) {
+  int no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
+  real *obs = ralloc(no), *traj = ralloc(nt);
+  orc_data *d = orc_data_create(m);
+  for (int i = 0; i < B; i++) {
+    load_state(m, d, s, i);
+    for (int k = 0; k < nb3; k++) d->xpos[k] = s->xpos[(size_t)i * nb3 + k];
+    for (int k = 0; k < 9; k++) d->xmat[9 + k] = s->xmat1[(size_t)i * 9 + k];
+    for (int k = 0; k < 3; k++) d->subtree_com[3 + k] = s->com1[(size_t)i * 3 + k];
+    for (int k = 0; k < m->nv; k++) d->qfrc_actuator[k] = s->qfrc_actuator[(size_t)i * m->nv + k];
+    env_glue(m, e, c, d, old_qpos + (size_t)i * m->nq, old_xpos + (size_t)i * nb3, obs, traj, s, i);
+  }
+  orc_data_destroy(d);
+  free(obs), free(traj);
   return 0;
 }
 

@@ -31,12 +31,16 @@ def golden_clip() -> dict:
     return {k: z[k] for k in z.files}
 
 
+def golden_qpos() -> np.ndarray:
+    """(250, 74) qpos rows of the shipped clip."""
+    g = golden_clip()
+    return np.concatenate([g["position"], g["quaternion"], g["joints"]], axis=1)
+
+
 @functools.lru_cache(maxsize=None)
 def reference_clip() -> pp.ReferenceClip:
     """66-body features rebuilt from the shipped clip's qpos."""
-    g = golden_clip()
-    q = np.concatenate([g["position"], g["quaternion"], g["joints"]], axis=1)
-    return pp.process_qpos(model(), q)
+    return pp.process_qpos(model(), golden_qpos())
 
 
 def env_kwargs() -> dict:

@@ -1,0 +1,260 @@
+"""Discriminating parity checks: product (HIP through the C-ABI, or the host simulation of the same source) vs the
+float64 oracle on IDENTICAL inputs, at the granularity where "within 1e-5" is a well-posed statement.
+
+The 6-iteration CG solve of the reference's configuration is not converged, so its result depends on a chain of
+discrete decisions (warm start, iteration counts, line-search bracket replacements, which rows are active at each
+trial step length).  A float32 implementation reproduces the float64 result to rounding as long as every decision
+comes out the same; where one flips, the result jumps by orders of magnitude more -- in ANY float32 implementation,
+the float32 build of the oracle included.  The checks therefore separate the two cases with the solver traces both
+sides record (csrc/vnl_types.h VNL_TRACE_*, oracle/vnl_oracle.c ORC_TRACE_*):
+
+  * substep resynchronised comparison (`resync_substeps`): ONE physics substep at a time, the oracle restarted from
+    the product's own state each time, so nothing compounds: every env whose decisions agree must match the oracle
+    within TOL_* of the array's scale; an env whose outputs deviate more WITHOUT a flipped decision is a failure;
+  * per-stage outputs of the forward pass from the LDS dump (`stage_errors`);
+  * the glue (obs / traj / reward terms / termination) on the product's own post-step state (`glue_errors`);
+  * the full control step with the per-substep traces (`control_step_flip_analysis`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import helpers as H
+
+# decision entries of one solver-iteration record (32 ints): [1] ls iterations, [2] swap bits, [3] pick, [4..24) counts
+_ITER_DECISIONS = slice(1, 24)
+
+
+def decisions_equal(tr_a: np.ndarray, tr_b: np.ndarray) -> np.ndarray:
+    """(..., TRACE_INTS) int arrays -> bool (...): same warm-start choice, iteration count and per-iteration decisions."""
+    a, b = np.asarray(tr_a), np.asarray(tr_b)
+    ok = (a[..., 0] == b[..., 0]) & (a[..., 1] == b[..., 1])
+    ia = a[..., 8:].reshape(*a.shape[:-1], -1, 32)[..., _ITER_DECISIONS]
+    ib = b[..., 8:].reshape(*b.shape[:-1], -1, 32)[..., _ITER_DECISIONS]
+    return ok & np.all(ia == ib, axis=(-1, -2))
+
+
+def describe_flip(tr_a: np.ndarray, tr_b: np.ndarray) -> str:
+    """First differing decision of two single-solve traces, human readable."""
+    if tr_a[0] != tr_b[0]:
+        return f"warm-start choice {tr_a[0]} vs {tr_b[0]}"
+    names = {1: "line-search iterations", 2: "bracket replacement bits", 3: "final pick (0 none / 1 lo / 2 hi)"}
+    for it in range((len(tr_a) - 8) // 32):
+        ra, rb = tr_a[8 + 32 * it: 40 + 32 * it], tr_b[8 + 32 * it: 40 + 32 * it]
+        if it >= max(tr_a[1], tr_b[1]):
+            break
+        if it >= min(tr_a[1], tr_b[1]):
+            return f"CG exit: {tr_a[1]} vs {tr_b[1]} iterations"
+        for k in range(4, 24):
+            if ra[k] != rb[k]:
+                return f"CG iteration {it}: active rows at trial step {k - 4}: {ra[k]} vs {rb[k]}"
+        for k in (1, 2, 3):
+            if ra[k] != rb[k]:
+                return f"CG iteration {it}: {names[k]} {ra[k]} vs {rb[k]}"
+    if tr_a[1] != tr_b[1]:
+        return f"CG exit: {tr_a[1]} vs {tr_b[1]} iterations"
+    return "none"
+
+
+def to_np(t) -> np.ndarray:
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def oracle_state_from(env, oracle, state) -> dict:
+    """Oracle batch state carrying the product's CURRENT pipeline state and frame counters (float64 copies)."""
+    B = env.num_envs
+    ost = oracle.new_state(B)
+    ps = state.pipeline_state
+    for k in ("qpos", "qvel", "act", "qacc_warmstart", "qfrc_actuator"):
+        ost[k][:] = to_np(getattr(ps, k)).astype(np.float64)
+    ost["xpos"][:] = to_np(ps.xpos).reshape(B, -1).astype(np.float64)
+    ost["xmat1"][:] = to_np(ps.xmat[:, 1]).reshape(B, 9).astype(np.float64)
+    ost["com1"][:] = to_np(ps.subtree_com_root).astype(np.float64)
+    ost["cur_frame"][:] = to_np(state.info["cur_frame"])
+    ost["sub_clip_frame"][:] = to_np(state.info["sub_clip_frame"])
+    return ost
+
+
+def per_env_scaled(a, ref) -> np.ndarray:
+    """max_k |a - ref| per env, divided by the scale of the whole reference array."""
+    a, ref = np.asarray(a, np.float64).reshape(len(ref), -1), np.asarray(ref, np.float64).reshape(len(ref), -1)
+    return np.max(np.abs(a - ref), axis=1) / max(float(np.max(np.abs(ref))), 1e-30)
+
+
+STATE_KEYS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "qfrc_actuator")
+
+
+def state_errors(state, ost) -> dict:
+    B = len(ost["qpos"])
+    ps = state.pipeline_state
+    out = {k: per_env_scaled(to_np(getattr(ps, k)).reshape(B, -1), ost[k]) for k in STATE_KEYS}
+    out["com1"] = per_env_scaled(to_np(ps.subtree_com_root), ost["com1"])
+    return out
+
+
+def _as_f32_state(ost: dict) -> dict:
+    return {k: (v.astype(np.float32) if v.dtype == np.float64 else v.copy()) for k, v in ost.items()}
+
+
+# Legitimacy bounds for followed decisions (oracle/vnl_oracle.c ORC_FOLLOW_REPORT), and the per-env error bound:
+# a product output may deviate from the float64 oracle (same decisions) by at most max(TOL, K_SENS x what the float32
+# build of the ORACLE deviates by on the same env with the same decisions) -- i.e. north_star's 1e-5 of the array's
+# scale wherever the env is well conditioned, and a bounded multiple of the env's own float32 rounding sensitivity
+# where the unconverged, stiff solve amplifies rounding beyond that.
+TOL = 1e-5
+K_SENS = 25.0
+LS_EXCESS_MAX = 2e-6     # followed line-search step may cost this fraction of the polynomial's scale more than natural
+EXIT_TIE_MAX = 1.0       # CG-exit disagreements must be within one float32-rounding unit of the exit threshold
+WARM_TIE_MAX = 2e-6      # warm-start disagreements: relative cost difference
+KINK_MARGIN_MAX = 2e-5   # a row whose activity differs at a trial step must sit this close to its switching point
+
+
+def follow_compare(env, o64, o32, state_before_fn, step_fn, action, n_frames):
+    """One product step (`step_fn()` -> new State, traces recorded) against the float64 and float32 oracles started
+    from the product's own pre-step state and made to FOLLOW the product's solver decisions.  Returns (err, dev32,
+    report): per-env scaled errors of the product vs o64, of o32 vs o64, and the legitimacy report [B][n_frames][8]."""
+    s64 = state_before_fn(o64)
+    s32 = _as_f32_state(s64)
+    st = step_fn()
+    ptr = env.solver_trace().numpy()
+    s64, _, rep = o64.env_step_follow(s64, action.astype(np.float64), ptr)
+    s32, _, _ = o32.env_step_follow(s32, action.astype(np.float32), ptr)
+    err = state_errors(st, s64)
+    dev = {k: per_env_scaled(s32[k].astype(np.float64), s64[k]) for k in STATE_KEYS}
+    dev["com1"] = per_env_scaled(s32["com1"].astype(np.float64), s64["com1"])
+    return st, err, dev, rep, s64
+
+
+def bound_violations(err: dict, dev: dict, tol=TOL, k=K_SENS) -> dict:
+    """{field: indices of envs with err > max(tol, k * dev)}"""
+    return {f: np.where(err[f] > np.maximum(tol, k * dev[f]))[0] for f in err}
+
+
+def legitimacy_summary(rep: np.ndarray) -> dict:
+    r = rep.reshape(-1, rep.shape[-1])
+    kink = r[:, 3] > 0
+    return dict(ls_excess=float(r[:, 0].max()), exit_tie=float(r[:, 1].max()), warm_tie=float(r[:, 2].max()),
+                kink_solves=int(kink.sum()), kink_margin=float(r[kink, 4].max()) if kink.any() else 0.0,
+                decisions_differing_mean=float(r[:, 5].mean()))
+
+
+def assert_legitimate(rep: np.ndarray) -> dict:
+    s = legitimacy_summary(rep)
+    assert s["ls_excess"] <= LS_EXCESS_MAX, s
+    assert s["exit_tie"] <= EXIT_TIE_MAX, s
+    assert s["warm_tie"] <= WARM_TIE_MAX, s
+    assert s["kink_margin"] <= KINK_MARGIN_MAX, s
+    return s
+
+
+def resync_substeps(env1, o64, o32, sf, noise, action, nsub=5):
+    """env1 / oracles: n_frames = 1.  Runs `nsub` consecutive substeps of the product; before each one the oracles are
+    reloaded with the product's own state, so every comparison is ONE substep on identical inputs (nothing compounds).
+    Returns one (err, dev32, report) per substep."""
+    env1.debug(2)
+    st = [env1.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))]
+    act_t = torch.from_numpy(action)
+    out = []
+    for _ in range(nsub):
+        new, err, dev, rep, _ = follow_compare(env1, o64, o32, lambda o: oracle_state_from(env1, o, st[0]),
+                                               lambda: env1.step(st[0], act_t), action, 1)
+        st[0] = new
+        out.append((err, dev, rep))
+    env1.debug(0)
+    return out
+
+
+def stage_errors(env, oracle, state_before, action, envs):
+    """Forward-pass stage outputs of the product (LDS image left by the last forward of a step, debug mode 2, taken
+    by the caller) against the oracle's forward on the same inputs, for the env indices `envs`.  `state_before`:
+    dict of numpy arrays (qpos, qvel, act, qacc_warmstart) the step started from; the env must have n_frames = 1.
+    Returns {name: per-env scaled error} plus the discrete sets (constraint-row presence, active contacts)."""
+    m = env.sys
+    nv, nefc, nlimit = int(m.scalars["nv"]), int(m.scalars["nefc"]), int(m.scalars["nlimit"])
+    ncon = int(m.scalars["ncon"])
+    sec = {k: to_np(env.scratch(k)) for k in ("qfrc_smooth", "qacc_smooth", "qacc", "qfrc_constraint", "efc_D", "Jaref",
+                                              "act_list")}
+    ctrl = np.clip(np.asarray(action, np.float64), -1.0, 1.0)
+    res = {k: [] for k in ("qfrc_smooth", "qacc_smooth", "efc_D", "Jaref", "qacc", "qfrc_constraint")}
+    rows_equal, contacts_equal, traces = [], [], []
+    ref_scale = {}
+    refs = {k: [] for k in res}
+    for i in envs:
+        oracle.set(qpos=state_before["qpos"][i], qvel=state_before["qvel"][i], act=state_before["act"][i],
+                   ctrl=ctrl[i], qacc_warmstart=state_before["qacc_warmstart"][i])
+        oracle.call("forward")
+        J = oracle.field("efc_J").reshape(nefc, nv)
+        present = np.abs(J).sum(1) > 0
+        D = np.abs(sec["efc_D"][i])  # limit rows carry the Jacobian sign on efc_D
+        rows_equal.append(bool(np.array_equal(D != 0, present)))
+        # active contact list: the first `na` bytes of the section are the contacts with D != 0, then their count
+        raw = np.ascontiguousarray(sec["act_list"][i]).view(np.uint8)
+        na = int(raw[4 * ((ncon + 3) // 4): 4 * ((ncon + 3) // 4) + 4].view(np.int32)[0])
+        want = [c for c in range(ncon) if present[nlimit + 4 * c]]
+        contacts_equal.append(list(raw[:na]) == want)
+        traces.append(oracle.solver_trace)
+        ref = dict(qfrc_smooth=oracle.field("qfrc_smooth").copy(), qacc_smooth=oracle.field("qacc_smooth").copy(),
+                   qacc=oracle.field("qacc").copy(), qfrc_constraint=oracle.field("qfrc_constraint").copy(),
+                   efc_D=np.where(present, oracle.field("efc_D"), 0.0),
+                   Jaref=np.where(present, J @ oracle.field("qacc") - oracle.field("efc_aref"), 0.0))
+        got = dict(qfrc_smooth=sec["qfrc_smooth"][i], qacc_smooth=sec["qacc_smooth"][i], qacc=sec["qacc"][i],
+                   qfrc_constraint=sec["qfrc_constraint"][i], efc_D=np.where(present, D, 0.0),
+                   Jaref=np.where(present, sec["Jaref"][i], 0.0))
+        for k in res:
+            res[k].append(np.max(np.abs(got[k] - ref[k])))
+            refs[k].append(np.max(np.abs(ref[k])))
+    for k in res:
+        ref_scale[k] = max(float(np.max(refs[k])), 1e-30)
+        res[k] = np.asarray(res[k]) / ref_scale[k]
+    return res, np.asarray(rows_equal), np.asarray(contacts_equal), np.asarray(traces)
+
+
+GLUE_KEYS = ("obs", "traj", "reward", "done", "termination_error")
+METRIC_NAMES = ("rcom", "rvel", "rtrunk", "rquat", "ract", "rapp", "termination_error")
+
+
+def _glue_run(env, oracle, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=False):
+    ost = oracle_state_from(env, oracle, state)
+    if f32:
+        ost = _as_f32_state(ost)
+    ost["cur_frame"][:] = old_cur_frame
+    ost["sub_clip_frame"][:] = old_sub_frame
+    oracle.env_glue(ost, old_qpos, old_xpos)
+    return ost
+
+
+def glue_errors(env, o64, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame):
+    """obs / traj / the reward terms / done / counters of the product's step against the oracle's glue evaluated on
+    the product's OWN post-step pipeline state (so physics sensitivity cannot mask a glue error).  Returns (err, dev32,
+    flags): per-env errors vs the float64 oracle scaled by each array's scale, the float32 oracle's own deviation from
+    the float64 one (rquat goes through arccos near 1, whose float32 conditioning is part of the reference's own
+    arithmetic), and the exact-equality flags."""
+    a = _glue_run(env, o64, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame)
+    b = _glue_run(env, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=True)
+    err = {"obs": per_env_scaled(to_np(state.obs), a["obs"]), "traj": per_env_scaled(to_np(state.info["traj"]), a["traj"])}
+    dev = {"obs": per_env_scaled(b["obs"], a["obs"]), "traj": per_env_scaled(b["traj"], a["traj"])}
+
+    def rel(x, ref):
+        return np.abs(np.asarray(x, np.float64) - ref) / max(float(np.max(np.abs(ref))), 1e-30)
+
+    for j, name in enumerate(METRIC_NAMES):
+        err[name], dev[name] = rel(to_np(state.metrics[name]), a["metrics"][:, j]), rel(b["metrics"][:, j], a["metrics"][:, j])
+    err["reward"], dev["reward"] = rel(to_np(state.reward), a["reward"]), rel(b["reward"], a["reward"])
+    err["info.termination_error"] = rel(to_np(state.info["termination_error"]), a["termination_error"])
+    dev["info.termination_error"] = rel(b["termination_error"], a["termination_error"])
+    flags = dict(done_equal=np.array_equal(to_np(state.done).astype(np.float64), a["done"]),
+                 frames_equal=(np.array_equal(to_np(state.info["cur_frame"]), a["cur_frame"]) and
+                               np.array_equal(to_np(state.info["sub_clip_frame"]), a["sub_clip_frame"])))
+    return err, dev, flags
+
+
+def control_step_follow(env, o64, o32, sf, noise, action):
+    """One full control step (n_frames substeps + glue) from a reset, product vs oracles following the product's
+    per-substep decisions.  Returns (state, err, dev32, report, oracle state)."""
+    env.debug(1)
+    st0 = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    res = follow_compare(env, o64, o32, lambda o: oracle_state_from(env, o, st0),
+                         lambda: env.step(st0, torch.from_numpy(action)), action, env._n_frames)
+    env.debug(0)
+    return res

@@ -206,13 +206,15 @@ struct EnvWave {
   vreal* s;  // LDS
   unsigned e, lane;
   const VNL_CAS KernelConsts* kc;
+  int* trace;  // debug only (vnl_env_debug): VNL_TRACE_INTS ints for the solver call of the current forward pass, or null
   // The same view with the constant block's address made opaque to the optimiser: constants read by the stage that
   // follows are loaded there (scalar loads) instead of being kept alive -- spilled to VGPR lanes and fetched back
   // with v_readlane -- from the top of the kernel.
+  VNL_HD EnvWave with_trace(int* t) const { return EnvWave{m, ev, st, L, s, e, lane, kc, t}; }
   VNL_HD EnvWave fresh() const {
     const VNL_CAS KernelConsts* k = kc;
     VNL_LAUNDER(k);
-    return EnvWave{k->m, k->ev, st, k->L, s, e, lane, k};
+    return EnvWave{k->m, k->ev, st, k->L, s, e, lane, k, trace};
   }
 #ifdef VNL_PROFILE
   VNL_HD void prof_begin() const {
@@ -1434,6 +1436,18 @@ struct EnvWave {
   struct LsRows {
     vreal ja[RPL], jv[RPL], a0[RPL], a1[RPL], a2[RPL];
   };
+  // debug trace only: rows of this lane that exist (D != 0) and are active at step length alpha, summed over the wave
+  template <int RPL>
+  VNL_HD int ls_count_active(const LsRows<RPL>& R, vreal alpha) const {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+      int r = (int)lane + j * VNL_LANES;
+      bool live = r < m.nefc && s[L.efc_D + (r < m.nefc ? r : 0)] != vreal(0.);
+      n += VNL_COUNT(live && R.ja[j] + alpha * R.jv[j] < vreal(0.));
+    }
+    return n;
+  }
   template <int RPL>
   VNL_HD void ls_load(LsRows<RPL>& R) const {
 #pragma unroll
@@ -1469,14 +1483,26 @@ struct EnvWave {
 
   // exact line search of solver._linesearch; returns the accepted step length (0 if no improvement)
   template <int RPL>
-  VNL_HD vreal line_search(vreal gauss, vreal qg1, vreal qg2, vreal gtol) const {
+  VNL_HD vreal line_search(vreal gauss, vreal qg1, vreal qg2, vreal gtol, int* tr /* debug trace of this iteration or null */) const {
       LsPoint p0, lo, hi;
       LsRows<RPL> rows;
       ls_load(rows);
       vreal a1[1] = {vreal(0.)};
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
+      if (tr) {
+        const int n0 = ls_count_active(rows, a1[0]);
+        VNL_SERIAL { tr[4] = n0; }
+      }
       a1[0] = p0.alpha - p0.d0 / p0.d1;
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
+      if (tr) {
+        const int n1 = ls_count_active(rows, a1[0]);
+        VNL_SERIAL { tr[5] = n1; }
+      }
+      if (tr) {
+        const int first_lo = lo.d0 < p0.d0;
+        VNL_SERIAL { tr[2] |= first_lo << 24; }
+      }
       if (lo.d0 < p0.d0) {
         hi = p0;
       } else {
@@ -1497,9 +1523,26 @@ struct EnvWave {
         bool s4 = (p[2].d0 > vreal(0.)) && (hi.d0 > p[2].d0);
         if (s4) hi = p[2];
         swap = s1 || s2 || s3 || s4;
+        if (tr) {
+          const int c0 = ls_count_active(rows, a3[0]), c1 = ls_count_active(rows, a3[1]), c2 = ls_count_active(rows, a3[2]);
+          VNL_SERIAL {
+            if (li < 6) {
+              tr[6 + 3 * li] = c0, tr[7 + 3 * li] = c1, tr[8 + 3 * li] = c2;
+              tr[2] |= ((int)s1 | (int)s2 << 1 | (int)s3 << 2 | (int)s4 << 3) << (4 * li);
+            }
+            tr[1] = li + 1;
+          }
+        }
       }
       bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-      return improved ? (lo.cost < hi.cost ? lo.alpha : hi.alpha) : vreal(0.);
+      const vreal accepted = improved ? (lo.cost < hi.cost ? lo.alpha : hi.alpha) : vreal(0.);
+      if (tr) {
+        VNL_SERIAL {
+          tr[0] = __builtin_bit_cast(int, (float)accepted);
+          tr[3] = improved ? (lo.cost < hi.cost ? 1 : 2) : 0;
+        }
+      }
+      return accepted;
   }
 
   // solver.solve (CG).  One env per wave: the while loops run with this env's own trip counts.
@@ -1519,6 +1562,9 @@ struct EnvWave {
     VNL_SYNC();
     vreal cost_w = fresh().constraint_cost(L.jv) + vreal(0.5) * gw;
     bool use_warm = cost_w < cost_s;
+    if (trace) {
+      VNL_FOR(k, VNL_TRACE_INTS) trace[k] = k == 0 ? (int)use_warm : 0;
+    }
     VNL_FOR(d, nv) {
       s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
       s[L.Ma + d] = use_warm ? s[L.mv + d] : s[L.smooth + d];
@@ -1562,8 +1608,13 @@ struct EnvWave {
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(18);
-      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol)
-                                              : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol);
+      int* tr = (trace && it < VNL_TRACE_ITERS) ? trace + 8 + 32 * it : nullptr;
+      if (trace) {
+        VNL_SYNC();  // (the zero fill above is by all lanes, the entries by lane 0)
+        VNL_SERIAL { trace[1] = it + 1; }
+      }
+      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
+                                              : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol, tr);
       VNL_FOR(d, nv) {
         s[L.qacc + d] += alpha * s[L.search + d];
         s[L.Ma + d] += alpha * s[L.mv + d];
@@ -1868,7 +1919,10 @@ struct EnvWave {
   }
 
   // RodentTracking.reset, rodent.py:119-176 (start_frame / noise supplied by the caller)
-  VNL_HD void reset(const int* start_frame, const vreal* noise) const {
+  VNL_HD int* trace_of(int* base, int f) const {
+    return base ? base + ((size_t)e * ev.n_frames + f) * VNL_TRACE_INTS : nullptr;
+  }
+  VNL_HD void reset(const int* start_frame, const vreal* noise, int* trace_base) const {
     load_tables();
     int clip = st.clip_id[e], sf = start_frame[e];
     int f = clampi(sf, 0, ev.T - 1), nj = m.nq - 7;
@@ -1883,7 +1937,7 @@ struct EnvWave {
     VNL_FOR(i, m.nu) s[L.act + i] = vreal(0.), s[L.ctrl + i] = vreal(0.);
     VNL_FOR(d, m.nv) s[L.qacc + d] = vreal(0.);
     VNL_SYNC();
-    forward(s + L.qacc);  // qacc_warmstart = 0 (mjx.make_data)
+    with_trace(trace_of(trace_base, 0)).forward(s + L.qacc);  // qacc_warmstart = 0 (mjx.make_data)
     store_state();
     write_traj(clip, sf);
     write_obs();
@@ -1897,7 +1951,8 @@ struct EnvWave {
   }
 
   // RodentTracking.step, rodent.py:178-239
-  VNL_HD void step(const vreal* action) const {
+  // dump_mid / trace_base: debug only (vnl_env_debug), null in normal use
+  VNL_HD void step(const vreal* action, vreal* dump_mid, int* trace_base) const {
     prof_begin();
     int clip = st.clip_id[e], old_frame = st.cur_frame[e], old_sub = st.sub_clip_frame[e];
     load_tables();
@@ -1914,7 +1969,8 @@ struct EnvWave {
     const vreal* gw = st.warm + (size_t)e * m.nv;
     VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
-      fresh().forward(f == 0 ? gw : s + L.qacc);
+      fresh().with_trace(trace_of(trace_base, f)).forward(f == 0 ? gw : s + L.qacc);
+      if (dump_mid && f == ev.n_frames - 1) dump(dump_mid);  // the LDS image as the last forward pass leaves it
       fresh().euler();
     }
     int new_frame = old_frame + 1, new_sub = old_sub + 1;

@@ -108,11 +108,29 @@ struct vnl_env {
   WsLayout L{};
   KernelConsts* kc = nullptr;  // device copy of {dm, de, L}
   vreal* dump = nullptr;  // [B][L.total] image of the per-env LDS, written only when debug is on
-  int debug = 0;
+  int* trace = nullptr;   // [B][n_frames][VNL_TRACE_INTS] solver decisions, written only when debug is on
+  int debug = 0;          // 0 off, 1 image at the end of reset / step, 2 image after the last forward pass of a step
   size_t lds_bytes = 0;
   int blocks_per_cu = 0;
   std::vector<void*> allocs;
   std::map<std::string, std::pair<int, int>> sections;  // name -> (offset, count)
+};
+
+// makes `device` current for the scope and restores the caller's device afterwards
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false, switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) return;
+    if (prev != device) {
+      if (hipSetDevice(device) != hipSuccess) return;
+      switched = true;
+    }
+    ok = true;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
 };
 
 template <class T, class S>
@@ -140,7 +158,9 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   d.iterations = (int)S("iterations"), d.ls_iterations = (int)S("ls_iterations"), d.eulerdamp = (int)S("eulerdamp");
   d.dt = (vreal)S("timestep"), d.tolerance = (vreal)S("tolerance"), d.ls_tolerance = (vreal)S("ls_tolerance");
   d.dbg_stage = 0, d.dbg_count = 0;
+#ifdef VNL_STAGE_KNOBS  // diagnostic library only: the product library reads no environment variables
   if (const char* dbg = getenv("VNL_DBG_REPEAT")) sscanf(dbg, "%d:%d", &d.dbg_stage, &d.dbg_count);
+#endif
   d.scale = (vreal)(S("meaninertia") * (d.nv > 1 ? d.nv : 1));
   const int nb = d.nbody, nj = d.njnt, nv = d.nv, nu = d.nu, ng = d.ncg;
   std::vector<int> nsub_host, limrow_host;  // kept for the per-dof contact ranges further down
@@ -489,7 +509,7 @@ static void layout(vnl_env* env) {
   L.total = (o + 3) & ~3;
 }
 
-__global__ void vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action, vreal* dump);
+__global__ void vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action, vreal* dump, vreal* dump_mid, int* trace);
 
 extern "C" void vnl_env_destroy(vnl_env* env) {
   if (!env) return;
@@ -504,7 +524,8 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(VNL_ERR_NO_DEVICE, "no HIP device: the rollout has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(VNL_ERR_ARG, "device ordinal out of range");
-  HIPCHK(hipSetDevice(device));
+  DeviceGuard guard(device);  // the caller's current device is restored on every return path
+  if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
   vnl_env* env = new vnl_env();
   env->device = device, env->B = num_envs;
   int rc = build_dev_model(env, hm);
@@ -553,10 +574,12 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
 #undef UP
   layout(env);
   env->lds_bytes = (size_t)env->L.total * sizeof(vreal);
+#ifdef VNL_STAGE_KNOBS
   if (const char* padk = getenv("VNL_DBG_LDS_BYTES")) {  // occupancy experiments only: force a larger LDS request
     size_t want = (size_t)atol(padk);
     if (want > env->lds_bytes) env->lds_bytes = want;
   }
+#endif
   if (6 * d.nbody > 512) {
     vnl_env_destroy(env);
     return fail(VNL_ERR_UNSUPPORTED, "more than 85 bodies (in-place tree prefix keeps 8 elements per lane)");
@@ -602,9 +625,14 @@ extern "C" int vnl_env_dims(const vnl_env* env, vnl_dims* o) {
 
 extern "C" int vnl_env_scratch(const vnl_env* env, const char* name, float** dev_ptr, int32_t* count) {
   if (!env || !name || !dev_ptr || !count) return fail(VNL_ERR_ARG, "vnl_env_scratch: null argument");
+  if (!env->dump) return fail(VNL_ERR_ARG, "scratch dump is off: call vnl_env_debug(env, 1) before reset/step");
+  if (strcmp(name, "solver_trace") == 0) {  // int32 [num_envs][n_frames][VNL_TRACE_INTS], contiguous (not inside the image)
+    *dev_ptr = (float*)env->trace;
+    *count = (env->de.n_frames > 0 ? env->de.n_frames : 1) * VNL_TRACE_INTS;
+    return VNL_OK;
+  }
   auto it = env->sections.find(name);
   if (it == env->sections.end()) return fail(VNL_ERR_ARG, "unknown scratch section %s", name);
-  if (!env->dump) return fail(VNL_ERR_ARG, "scratch dump is off: call vnl_env_debug(env, 1) before reset/step");
   *dev_ptr = (float*)(env->dump + it->second.first);
   *count = it->second.second;
   return VNL_OK;
@@ -612,13 +640,19 @@ extern "C" int vnl_env_scratch(const vnl_env* env, const char* name, float** dev
 
 extern "C" int vnl_env_debug(vnl_env* env, int32_t enable, int32_t* row_stride) {
   if (!env) return fail(VNL_ERR_ARG, "vnl_env_debug: null argument");
+  if (enable < 0 || enable > 2) return fail(VNL_ERR_ARG, "vnl_env_debug: mode must be 0, 1 or 2");
   if (enable && !env->dump) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, (size_t)env->L.total * env->B * sizeof(vreal)));
     env->allocs.push_back(p);
     env->dump = (vreal*)p;
+    const size_t nt = (size_t)env->B * (env->de.n_frames > 0 ? env->de.n_frames : 1) * VNL_TRACE_INTS * sizeof(int);
+    HIPCHK(hipMalloc(&p, nt));
+    env->allocs.push_back(p);
+    HIPCHK(hipMemset(p, 0, nt));
+    env->trace = (int*)p;
   }
-  env->debug = enable ? 1 : 0;
+  env->debug = enable;
   if (row_stride) *row_stride = env->L.total;
   return VNL_OK;
 }
@@ -626,21 +660,26 @@ extern "C" int vnl_env_debug(vnl_env* env, int32_t enable, int32_t* row_stride) 
 // ----------------------------------------------------------------------------- kernels
 // One env per 64-lane workgroup; the env's whole working set lives in dynamic LDS (~25 KB ->
 // 6 workgroups per CU, 1536 envs in flight on 256 CUs).
-__global__ void __launch_bounds__(64) vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action,
-                                                      vreal* dump) {
+// (VNL_KERNEL_ATTR: empty in the product; csrc/build.py --spill sets a VGPR cap to force register spills to scratch,
+// the regression build for the "results must not depend on spilling" test)
+#ifndef VNL_KERNEL_ATTR
+#define VNL_KERNEL_ATTR
+#endif
+__global__ void __launch_bounds__(64) VNL_KERNEL_ATTR vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action,
+                                                      vreal* dump, vreal* dump_mid, int* trace) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k};
-  w.step(action);
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
+  w.step(action, dump_mid, trace);
   if (dump) w.dump(dump);
 }
 
-__global__ void __launch_bounds__(64) vnl_reset_kernel(const KernelConsts* kc, DevState st, const int* start_frame,
-                                                       const vreal* noise, vreal* dump) {
+__global__ void __launch_bounds__(64) VNL_KERNEL_ATTR vnl_reset_kernel(const KernelConsts* kc, DevState st, const int* start_frame,
+                                                       const vreal* noise, vreal* dump, int* trace) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k};
-  w.reset(start_frame, noise);
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
+  w.reset(start_frame, noise, trace);
   if (dump) w.dump(dump);
 }
 
@@ -666,8 +705,11 @@ extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const flo
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
+  DeviceGuard guard(env->device);  // the launch goes to the env's GPU whatever the caller's current device is
+  if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
   hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
-                     (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr);
+                     (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr,
+                     env->debug ? env->trace : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }
@@ -677,8 +719,11 @@ extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* 
   DevState ds;
   int rc = to_dev_state(state, &ds);
   if (rc != VNL_OK) return rc;
+  DeviceGuard guard(env->device);
+  if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
   hipLaunchKernelGGL(vnl_step_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
-                     (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug ? env->dump : nullptr);
+                     (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug == 1 ? env->dump : nullptr,
+                     env->debug == 2 ? env->dump : nullptr, env->debug ? env->trace : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

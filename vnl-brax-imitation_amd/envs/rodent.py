@@ -275,11 +275,31 @@ class RodentTracking(Env):
         return state
 
     # --- bisection hook -----------------------------------------------------------------------
-    def debug(self, enable: bool = True) -> None:
-        """With debug on, every reset/step also dumps the per-env LDS image for `scratch()`."""
+    def debug(self, mode=True) -> None:
+        """Bisection hooks.  mode 1 (True): every reset/step also dumps the per-env LDS image at the end of the
+        kernel; mode 2: `step` dumps it as its LAST forward pass leaves it (before the Euler update reuses the
+        constraint rows' space), `reset` at its end as before.  Either mode also records the solver's discrete
+        decisions (`solver_trace()`).  0 / False: off."""
         stride = C.c_int32()
-        _lib.check(self._L, self._L.vnl_env_debug(self._env_h, int(enable), C.byref(stride)))
+        _lib.check(self._L, self._L.vnl_env_debug(self._env_h, int(mode), C.byref(stride)))
         self._dump_stride = stride.value
+
+    def solver_trace(self) -> torch.Tensor:
+        """(B, n_frames, VNL_TRACE_INTS) int32: discrete decisions of the solver call of every substep of the last
+        step (row 0 only after a reset); layout in csrc/vnl_types.h."""
+        ptr, cnt = C.c_void_p(), C.c_int32()
+        _lib.check(self._L, self._L.vnl_env_scratch(self._env_h, b"solver_trace", C.byref(ptr), C.byref(cnt)))
+        B, n = self.num_envs, cnt.value
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+            flat = torch.empty(B * n, dtype=torch.int32, device=self.device)
+            rc = C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(flat.data_ptr()), ptr, C.c_size_t(4 * B * n), C.c_int(3))
+            if rc != 0:
+                raise _lib.VnlError(f"hipMemcpy failed: {rc}")
+            flat = flat.cpu()
+        else:
+            flat = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(B * n,)).copy())
+        return flat.view(B, max(self._n_frames, 1), -1)
 
     def scratch(self, name: str) -> torch.Tensor:
         """(B, count) copy of a named per-env scratch section left by the last reset/step (debug on)."""

@@ -78,18 +78,57 @@ def compute_velocity_from_kinematics(qpos_trajectory: np.ndarray, dt: float) -> 
     return np.concatenate([qvel_translation, qvel_gyro, qvel_joints], axis=1).astype(np.float32)
 
 
+def _qmul(u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    return tr.quat_mul(u, v)
+
+
+def _qrot(v: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """MJX math.rotate, batched: v (..., 3) by q (..., 4)."""
+    s, u = q[..., :1], q[..., 1:]
+    return 2.0 * np.sum(u * v, -1, keepdims=True) * u + (s * s - np.sum(u * u, -1, keepdims=True)) * v + \
+        2.0 * s * np.cross(u, v)
+
+
+def forward_kinematics_batch(model: mjcf.CompiledModel, qpos: np.ndarray):
+    """smooth.kinematics for N frames at once (float64): the per-frame loop of the reference's process_clip
+    (mjx_preprocess.py:85-107 scans mjx.kinematics over the frames) vectorised over the frame axis; same arithmetic as
+    model.mjcf.forward_kinematics.  Returns (qpos with normalised root quaternion, xpos (N, nbody, 3), xquat (N, nbody, 4))."""
+    a = model.arrays
+    nbody = int(model.scalars["nbody"])
+    q = np.array(qpos, dtype=np.float64)
+    N = q.shape[0]
+    xpos = np.zeros((N, nbody, 3))
+    xquat = np.zeros((N, nbody, 4))
+    xquat[:, 0, 0] = 1.0
+    for b in range(1, nbody):
+        p = int(a["body_parentid"][b])
+        pos = xpos[:, p] + _qrot(np.broadcast_to(a["body_pos"][b], (N, 3)), xquat[:, p])
+        quat = _qmul(xquat[:, p], np.broadcast_to(a["body_quat"][b], (N, 4)))
+        for k in range(int(a["body_jntnum"][b])):
+            j = int(a["body_jntadr"][b]) + k
+            qa = int(a["jnt_qposadr"][j])
+            if a["jnt_type"][j] == mjcf.JNT_FREE:
+                pos = q[:, qa:qa + 3].copy()
+                quat = q[:, qa + 3:qa + 7] / np.linalg.norm(q[:, qa + 3:qa + 7], axis=1, keepdims=True)
+                q[:, qa + 3:qa + 7] = quat
+            else:
+                jp, ax = np.broadcast_to(a["jnt_pos"][j], (N, 3)), a["jnt_axis"][j]
+                anchor = _qrot(jp, quat) + pos
+                half = 0.5 * (q[:, qa] - a["qpos0"][qa])
+                dq = np.concatenate([np.cos(half)[:, None], np.sin(half)[:, None] * ax[None, :]], axis=1)
+                quat = _qmul(quat, dq)
+                pos = anchor - _qrot(jp, quat)
+        xpos[:, b] = pos
+        xquat[:, b] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    return q, xpos, xquat
+
+
 def process_qpos(model: mjcf.CompiledModel, mocap_qpos: np.ndarray, max_qvel: float = 20.0,
                  dt: float = 0.02) -> ReferenceClip:
     """Feature extraction for one clip given its (T, nq) qpos rows (mjx_preprocess.py:85-107,110-134)."""
     mocap_qpos = np.asarray(mocap_qpos, dtype=np.float32)
-    T = mocap_qpos.shape[0]
-    nbody = int(model.scalars["nbody"])
-    xpos = np.zeros((T, nbody, 3), np.float32)
-    xquat = np.zeros((T, nbody, 4), np.float32)
-    qn = np.zeros_like(mocap_qpos)
-    for t in range(T):
-        fk = mjcf.forward_kinematics(model, mocap_qpos[t].astype(np.float64))
-        xpos[t], xquat[t], qn[t] = fk["xpos"], fk["xquat"], fk["qpos"]
+    qn, xpos, xquat = forward_kinematics_batch(model, mocap_qpos.astype(np.float64))
+    qn, xpos, xquat = qn.astype(np.float32), xpos.astype(np.float32), xquat.astype(np.float32)
     padded = np.concatenate([mocap_qpos, mocap_qpos[-1:]], axis=0)
     qvel = compute_velocity_from_kinematics(padded, dt)
     qvel[:, 6:] = np.clip(qvel[:, 6:], -max_qvel, max_qvel)
@@ -97,6 +136,30 @@ def process_qpos(model: mjcf.CompiledModel, mocap_qpos: np.ndarray, max_qvel: fl
         position=qn[:, :3], quaternion=qn[:, 3:7], joints=qn[:, 7:], body_positions=xpos, body_quaternions=xquat,
         velocity=qvel[:, :3], angular_velocity=qvel[:, 3:6], joints_velocity=qvel[:, 6:],
     )
+
+
+def synthesize_clips(model: mjcf.CompiledModel, qpos: np.ndarray, num_clips: int, seed: int = 0,
+                     max_qvel: float = 20.0, dt: float = 0.02) -> ReferenceClip:
+    """Multi-clip container of `num_clips` clips synthesised from ONE clip's (T, nq) qpos rows (SURVEY 8(d) config 4:
+    the reference has only a stub for its multi-clip env, rodent.py:473-475, and its 842-clip file is not shipped): clip 0
+    is the source itself; every further clip is the source under a random yaw rotation about the vertical axis, a random
+    horizontal translation and, for about half of them, time reversal (all seeded), re-run through process_qpos."""
+    rng = np.random.default_rng(seed)
+    src = np.asarray(qpos, dtype=np.float64)
+    clips = []
+    for c in range(num_clips):
+        q = src.copy()
+        if c > 0:
+            yaw, shift, rev = rng.uniform(-np.pi, np.pi), rng.uniform(-0.5, 0.5, 2), bool(rng.integers(0, 2))
+            if rev:
+                q = q[::-1].copy()
+            cz, sz = np.cos(yaw), np.sin(yaw)
+            x, y = q[:, 0].copy(), q[:, 1].copy()
+            q[:, 0], q[:, 1] = cz * x - sz * y + shift[0], sz * x + cz * y + shift[1]
+            qy = np.array([np.cos(0.5 * yaw), 0.0, 0.0, np.sin(0.5 * yaw)])
+            q[:, 3:7] = tr.quat_mul(np.broadcast_to(qy, (len(q), 4)), q[:, 3:7])
+        clips.append(process_qpos(model, q, max_qvel=max_qvel, dt=dt))
+    return ReferenceClip.stack(clips)
 
 
 def process_clip(stac_path: str, scale_factor: float = 0.9, start_step: int = 0, clip_length: int = 250,
