@@ -146,7 +146,7 @@ int vnl_env_step(vnl_env*, const float* action, const vnl_state* state, void* st
  * update reuses the space of the constraint rows; 0 = off.  vnl_env_scratch returns the device
  * pointer of a named section inside row 0 ("qLD", "qfrc_smooth", "qacc_smooth", "qacc",
  * "efc_D", "Jaref", "qfrc_constraint", ...) and its element count; env e is at +e*row_stride.
- * The section "solver_trace" is separate from the image: int32 [num_envs][n_frames][264], the
+ * The section "solver_trace" is separate from the image: int32 [num_envs][n_frames][536], the
  * discrete decisions (warm start, iteration counts, line-search bracket decisions, active-row
  * counts) of the solver call of every substep, layout in csrc/vnl_types.h (VNL_TRACE_*). */
 int vnl_env_debug(vnl_env*, int32_t enable, int32_t* row_stride);

@@ -209,14 +209,14 @@ class Oracle:
 
     def env_step_follow(self, st: dict, action: np.ndarray, follow: np.ndarray):
         """env_step whose solver takes its discrete decisions from `follow` ([B][n_frames][trace_ints] int32, another
-        implementation's trace) instead of its own comparisons.  Returns (st, trace, report[B][n_frames][8]); the
+        implementation's trace) instead of its own comparisons.  Returns (st, trace, report[B][n_frames][12]); the
         report says whether the followed decisions were legitimate (layout: vnl_oracle.c, ORC_FOLLOW_REPORT)."""
         B = st["qpos"].shape[0]
         a = np.ascontiguousarray(action, dtype=self.real)
         f = np.ascontiguousarray(follow, dtype=np.int32).reshape(B, self.spec.n_frames, self.trace_ints)
         cs = self._cstate(st)
         tr = np.zeros((B, self.spec.n_frames, self.trace_ints), dtype=np.int32)
-        rep = np.zeros((B, self.spec.n_frames, 8), dtype=self.real)
+        rep = np.zeros((B, self.spec.n_frames, 12), dtype=self.real)
         rc = self.lib.orc_env_step_follow(self.model, C.byref(self.spec), C.byref(self._clip), B, a.ctypes.data,
                                           C.byref(cs), tr.ctypes.data, f.ctypes.data, rep.ctypes.data)
         assert rc == 0

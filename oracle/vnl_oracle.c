@@ -96,12 +96,14 @@ int orc_get_option(const char *name) {
 /* Solver trace: the DISCRETE decisions of one solver.solve call, so that a test can tell "same decisions, same
  * numbers" from "a decision flipped" (the 6-iteration CG is not converged, so a flipped decision moves the result
  * by far more than rounding).  Same layout as the product's debug trace (csrc/vnl_body.h, VNL_TRACE_*):
- * [0] warm start used, [1] iterations, then per iteration 32 ints: [0] float32 bits of the accepted step length,
+ * [0] warm start used, [1] iterations, then per iteration 64 ints: [0] float32 bits of the accepted step length,
  * [1] line-search iterations, [2] the four replacement decisions of every line-search iteration (4 bits each),
  * [3] pick (0 none, 1 lo, 2 hi), [4..24) rows active at every trial step length (p0, first Newton point, then
  * lo_next / hi_next / mid per line-search iteration). */
 #define ORC_TRACE_ITERS 8
-#define ORC_TRACE_INTS (8 + 32 * ORC_TRACE_ITERS)
+#define ORC_TRACE_REC 64 /* ints per iteration record */
+#define ORC_TRACE_ROWS (8 + ORC_TRACE_REC * ORC_TRACE_ITERS) /* then 16 ints: bit r set = constraint row r present (not masked out) */
+#define ORC_TRACE_INTS (ORC_TRACE_ROWS + 16)
 
 #define JNT_FREE 0
 #define JNT_HINGE 3
@@ -272,7 +274,7 @@ typedef struct orc_data {
   int trace[ORC_TRACE_INTS]; /* discrete decisions of the last solve (layout above) */
   int *row_live;             /* nefc: row not masked out by make_constraint */
   const int *follow;         /* NULL, or a trace whose decisions the next solve takes instead of its own */
-  real follow_report[8];     /* legitimacy of the followed decisions (see slv section) */
+  real follow_report[12];    /* legitimacy of the followed decisions (see slv section) */
   /* scratch */
   real *w0, *w1, *w2, *w3, *w4, *w5, *wefc0, *wefc1, *quad;
   real *arena;
@@ -697,6 +699,14 @@ void orc_make_constraint(const orc_model *m, orc_data *d) {
     real q = d->qpos[qa], dmin = q - m->jnt_range[2 * j], dmax = m->jnt_range[2 * j + 1] - q;
     real pos = (dmin < dmax ? dmin : dmax) - m->jnt_margin[j];
     int active = pos < 0;
+    if (d->follow && r < 512) {
+      int f = (d->follow[ORC_TRACE_ROWS + (r >> 5)] >> (r & 31)) & 1;
+      if (f != active) {
+        d->follow_report[6] += 1;
+        if (RFABS(pos) > d->follow_report[7]) d->follow_report[7] = RFABS(pos);
+        active = f;
+      }
+    }
     d->efc_J[r * nv + da] = active ? (dmin < dmax ? (real)1 : (real)-1) : 0;
     d->row_live[r] = active;
     d->efc_pos[r] = (active || !g_opt.inactive_pos_zero) ? pos : 0;
@@ -725,6 +735,14 @@ void orc_make_constraint(const orc_model *m, orc_data *d) {
       int c = m->cg_conadr[g] + s;
       real dist = d->con_dist[c] - m->cg_margin[g];
       int active = dist < 0;
+      if (d->follow && r < 512) {
+        int f = (d->follow[ORC_TRACE_ROWS + (r >> 5)] >> (r & 31)) & 1;
+        if (f != active) {
+          d->follow_report[6] += 1;
+          if (RFABS(dist) > d->follow_report[7]) d->follow_report[7] = RFABS(dist);
+          active = f;
+        }
+      }
       jacp_point(m, d, jac, d->con_pos + 3 * c, b); /* body1 = world -> zero */
       const real *fr = d->con_frame + 9 * c;
       for (int t2 = 0; t2 < 2; t2++)
@@ -876,6 +894,7 @@ void orc_acceleration(const orc_model *m, orc_data *d) {
 typedef struct {
   real *qacc, *Ma, *Jaref, *grad, *Mgrad, *search, *qfrc_constraint, *efc_force;
   real gauss, cost, prev_cost;
+  real cost_scale, prev_cost_scale; /* sum of the magnitudes of the terms `cost` is made of: its rounding error is eps x this */
 } slv_ctx;
 
 static void slv_update_constraint(const orc_model *m, const orc_data *d, slv_ctx *c) {
@@ -891,11 +910,15 @@ static void slv_update_constraint(const orc_model *m, const orc_data *d, slv_ctx
     for (int r = 0; r < ne; r++) s += d->efc_J[r * nv + i] * c->efc_force[r];
     c->qfrc_constraint[i] = s;
   }
-  real g = 0;
-  for (int i = 0; i < nv; i++) g += (c->Ma[i] - d->qfrc_smooth[i]) * (c->qacc[i] - d->qacc_smooth[i]);
+  real g = 0, gs = 0;
+  for (int i = 0; i < nv; i++) {
+    g += (c->Ma[i] - d->qfrc_smooth[i]) * (c->qacc[i] - d->qacc_smooth[i]);
+    gs += (RFABS(c->Ma[i]) + RFABS(d->qfrc_smooth[i])) * (RFABS(c->qacc[i]) + RFABS(d->qacc_smooth[i]));
+  }
   c->gauss = (real)0.5 * g;
-  c->prev_cost = c->cost;
+  c->prev_cost = c->cost, c->prev_cost_scale = c->cost_scale;
   c->cost = (real)0.5 * cost + c->gauss;
+  c->cost_scale = (real)0.5 * cost + (real)0.5 * gs;
 }
 
 static void slv_update_gradient(const orc_model *m, const orc_data *d, slv_ctx *c) {
@@ -912,7 +935,7 @@ static void slv_init(const orc_model *m, const orc_data *d, slv_ctx *c, const re
     c->Jaref[r] = s - d->efc_aref[r];
   }
   mul_m(m, d, c->Ma, qacc);
-  c->cost = INFINITY, c->prev_cost = 0;
+  c->cost = INFINITY, c->prev_cost = 0, c->cost_scale = 0, c->prev_cost_scale = 0;
   slv_update_constraint(m, d, c);
 }
 
@@ -927,17 +950,23 @@ typedef struct {
  * evaluates the SAME branch of the algorithm and its float64 numbers can be compared with the other side's float32
  * numbers at rounding level.  Whether the followed decisions were legitimate is judged separately and reported in
  * d->follow_report:
- *   [0] worst line search: (cost(alpha followed) - cost(alpha natural)) / (|q0| + |alpha q1| + |alpha^2 q2|), where
- *       "natural" is this oracle's own float64 line search from the same state: > ~1e-6 means the followed step was
- *       worse than rounding can explain;
- *   [1] worst CG-exit disagreement: distance of the natural exit test from its threshold, in units of the float32
- *       rounding of the costs, 0 if the exit iteration agreed;
- *   [2] warm-start disagreement: |cost_warm - cost_smooth| / (|cost_warm| + |cost_smooth|), 0 if the choice agreed;
+ * All three tie measures are in units of 1e-6 x the sum of the magnitudes of the terms the compared quantity is a sum
+ * of (~16 float32 roundings of it: the cost has a Gauss term 0.5 (Ma - f).(a - a_smooth) that cancels heavily), so <= 1
+ * means "a float32 evaluation cannot tell the two sides apart":
+ *   [0] worst line search: cost(alpha followed) - cost(alpha natural), where "natural" is this oracle's own float64
+ *       line search from the same state;
+ *   [1] worst CG-exit disagreement: distance of the natural exit test (improvement or gradient) from its threshold,
+ *       0 if the exit iteration agreed;
+ *   [2] warm-start disagreement: |cost_warm - cost_smooth|, 0 if the choice agreed;
  *   [3] number of trial step lengths at which the set of active rows had a different size;
- *   [4] the largest, over those, of min_r |Jaref_r + alpha jv_r| / (|Jaref_r| + |alpha jv_r|): how far from its
- *       switching point the nearest row was (rounding-sized: a row sat on its kink);
- *   [5] number of followed decisions that differ from the natural ones. */
-#define ORC_FOLLOW_REPORT 8
+ *   [4] the largest, over those, of min_r |Jaref_r + alpha jv_r| / (|(J qacc)_r| + |aref_r| + |alpha jv_r|): how far
+ *       from its switching point the nearest row was, relative to the terms it is made of (rounding-sized: a row
+ *       sat on its kink);
+ *   [5] number of followed decisions that differ from the natural ones;
+ *   [6] constraint rows whose presence was followed against this oracle's own test (limit violated / geom in contact);
+ *   [7] the largest |violation depth| among those (rounding-sized: the joint / geom sat on its threshold);
+ *   [8] the largest relative distance between a trial step length of this oracle and the followed side's. */
+#define ORC_FOLLOW_REPORT 12
 
 static ls_point ls_eval(const orc_model *m, const orc_data *d, const slv_ctx *c, const real *jv, const real *quad,
                         const real *quad_gauss, real alpha, int *nactive, real *kink) {
@@ -949,7 +978,8 @@ static ls_point ls_eval(const orc_model *m, const orc_data *d, const slv_ctx *c,
     if (x < 0) q0 += quad[3 * r], q1 += quad[3 * r + 1], q2 += quad[3 * r + 2];
     if ((nactive || kink) && d->row_live[r]) { /* rows make_constraint did not mask out */
       if (x < 0) na++;
-      real den = RFABS(c->Jaref[r]) + RFABS(alpha * jv[r]);
+      /* x = (J qacc)_r - aref_r + alpha jv_r: distance from the switching point relative to the terms it is made of */
+      real den = RFABS(c->Jaref[r] + d->efc_aref[r]) + RFABS(d->efc_aref[r]) + RFABS(alpha * jv[r]);
       if (den > 0 && RFABS(x) / den < near) near = RFABS(x) / den;
     }
   }
@@ -969,15 +999,33 @@ static real ls_run(const orc_model *m, orc_data *d, const slv_ctx *c, const real
                    real gtol, int *tr, const int *fol, real *report) {
   int nev = 0, cnt = 0;
   real kink = 1;
-#define EVAL(alpha_) ls_eval(m, d, c, jv, quad, qg, (alpha_), &cnt, &kink)
-#define NOTE()                                                         \
-  do {                                                                 \
-    if (tr && nev < 20) tr[4 + nev] = cnt;                             \
-    if (fol && report && nev < 20 && fol[4 + nev] != cnt) {            \
-      report[3] += 1;                                                  \
-      if (kink > report[4]) report[4] = kink;                          \
-    }                                                                  \
-    nev++;                                                             \
+  real cur_alpha = 0;
+#define EVAL(alpha_) (cur_alpha = (alpha_), ls_eval(m, d, c, jv, quad, qg, cur_alpha, &cnt, &kink))
+  /* following: the number of active rows is compared AT THE OTHER SIDE'S trial step length (its float32 bits are in
+   * the record), so that a mismatch can only come from a row sitting on its switching point; how far the two sides'
+   * trial step lengths are apart is reported separately ([8] of the report, relative to the larger of them) */
+#define NOTE()                                                                              \
+  do {                                                                                      \
+    if (tr && nev < 20) {                                                                   \
+      float a32_ = (float)cur_alpha;                                                        \
+      tr[4 + nev] = cnt;                                                                    \
+      memcpy(&tr[24 + nev], &a32_, 4);                                                      \
+    }                                                                                       \
+    if (fol && report && nev < 20) {                                                        \
+      float fa_;                                                                            \
+      memcpy(&fa_, &fol[24 + nev], 4);                                                      \
+      int cnt_f_ = 0;                                                                       \
+      real kink_f_ = 1;                                                                     \
+      (void)ls_eval(m, d, c, jv, quad, qg, (real)fa_, &cnt_f_, &kink_f_);                   \
+      if (fol[4 + nev] != cnt_f_) {                                                         \
+        report[3] += 1;                                                                     \
+        if (kink_f_ > report[4]) report[4] = kink_f_;                                       \
+      }                                                                                     \
+      real am_ = RFABS(cur_alpha) > RFABS((real)fa_) ? RFABS(cur_alpha) : RFABS((real)fa_); \
+      real da_ = am_ > 0 ? RFABS(cur_alpha - (real)fa_) / am_ : 0;                          \
+      if (da_ > report[8]) report[8] = da_;                                                 \
+    }                                                                                       \
+    nev++;                                                                                  \
   } while (0)
   ls_point p0 = EVAL(0);
   NOTE();
@@ -1100,11 +1148,11 @@ static void slv_linesearch(const orc_model *m, orc_data *d, slv_ctx *c, int *tr 
   if (fol && report) { /* how much worse than this oracle's own line search is the followed step? */
     real a_nat = ls_run(m, d, c, jv, quad, qg, gtol, NULL, NULL, NULL);
     ls_point pf = ls_eval(m, d, c, jv, quad, qg, alpha, NULL, NULL), pn = ls_eval(m, d, c, jv, quad, qg, a_nat, NULL, NULL);
-    ls_point pz = ls_eval(m, d, c, jv, quad, qg, 0, NULL, NULL);
-    real q1 = pz.deriv_0, q2 = (real)0.5 * pz.deriv_1; /* coefficients at alpha = 0: the scale of the polynomial */
     real am = RFABS(alpha) > RFABS(a_nat) ? RFABS(alpha) : RFABS(a_nat);
-    real scale = RFABS(pz.cost) + RFABS(am * q1) + RFABS(am * am * q2);
-    real excess = scale > 0 ? (pf.cost - pn.cost) / scale : 0;
+    real scale = c->cost_scale + am * am * RFABS(qg[2]); /* magnitudes of the terms of the polynomial at |alpha| = am */
+    for (int i = 0; i < nv; i++) scale += am * RFABS(c->search[i]) * (RFABS(c->Ma[i]) + RFABS(d->qfrc_smooth[i]));
+    for (int r = 0; r < ne; r++) scale += RFABS(am * quad[3 * r + 1]) + am * am * RFABS(quad[3 * r + 2]);
+    real excess = (pf.cost - pn.cost) / ((real)1e-6 * scale + MJ_MINVAL);
     if (excess > report[0]) report[0] = excess;
   }
   if (alpha != 0) {
@@ -1117,25 +1165,29 @@ void orc_solve(const orc_model *m, orc_data *d) {
   int nv = m->nv, ne = m->nefc;
   const int *fol = d->follow;
   real *report = fol ? d->follow_report : NULL;
-  if (report) memset(report, 0, sizeof(real) * ORC_FOLLOW_REPORT);
+  if (report) { /* [6], [7] were written by make_constraint of this forward pass */
+    memset(report, 0, sizeof(real) * 6);
+    memset(report + 8, 0, sizeof(real) * 4);
+  }
   slv_ctx c;
   c.qacc = ralloc(nv), c.Ma = ralloc(nv), c.Jaref = ralloc(ne), c.grad = ralloc(nv), c.Mgrad = ralloc(nv);
   c.search = ralloc(nv), c.qfrc_constraint = ralloc(nv), c.efc_force = ralloc(ne);
   /* warmstart: pick the cheaper of qacc_warmstart and qacc_smooth */
   slv_init(m, d, &c, d->qacc_warmstart);
-  real cost_warm = c.cost;
+  real cost_warm = c.cost, scale_warm = c.cost_scale;
   slv_init(m, d, &c, d->qacc_smooth);
-  real cost_smooth = c.cost;
+  real cost_smooth = c.cost, scale_smooth = c.cost_scale;
   int use_warm = cost_warm < cost_smooth;
   if (fol && fol[0] != use_warm) {
-    real den = RFABS(cost_warm) + RFABS(cost_smooth);
-    report[2] = den > 0 ? RFABS(cost_warm - cost_smooth) / den : 0;
+    report[2] = RFABS(cost_warm - cost_smooth) / ((real)1e-6 * (scale_warm + scale_smooth) + MJ_MINVAL);
     report[5] += 1;
     use_warm = fol[0];
   }
   const real *start = use_warm ? d->qacc_warmstart : d->qacc_smooth;
   memset(d->trace, 0, sizeof(d->trace));
   d->trace[0] = use_warm;
+  for (int r = 0; r < ne && r < 512; r++)
+    if (d->row_live[r]) d->trace[ORC_TRACE_ROWS + (r >> 5)] |= 1 << (r & 31);
   slv_init(m, d, &c, start);
   slv_update_gradient(m, d, &c);
   for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i];
@@ -1154,8 +1206,13 @@ void orc_solve(const orc_model *m, orc_data *d) {
       int fdone = niter >= fol[1];
       if (fdone != done) {
         /* distance of the two exit tests from their thresholds, in units of the float32 rounding of their operands */
-        real r_imp = RFABS(c.prev_cost - c.cost - m->tolerance * scale) / ((real)1e-6 * (RFABS(c.prev_cost) + RFABS(c.cost)) + MJ_MINVAL);
-        real r_grd = RFABS(gradient - m->tolerance) / ((real)1e-5 * gradient + MJ_MINVAL);
+        real r_imp = RFABS(c.prev_cost - c.cost - m->tolerance * scale) / ((real)1e-6 * (c.prev_cost_scale + c.cost_scale) + MJ_MINVAL);
+        real gs = 0;
+        for (int i = 0; i < nv; i++) {
+          real t = RFABS(c.Ma[i]) + RFABS(d->qfrc_smooth[i]) + RFABS(c.qfrc_constraint[i]);
+          gs += t * t;
+        }
+        real r_grd = RFABS(gradient - m->tolerance) / ((real)1e-6 * RSQRT(gs) / scale + MJ_MINVAL);
         real r = r_imp < r_grd ? r_imp : r_grd;
         if (!isfinite((double)c.prev_cost)) r = r_grd; /* first pass: prev_cost = inf, only the gradient test can fire */
         if (r > report[1]) report[1] = r;
@@ -1164,8 +1221,8 @@ void orc_solve(const orc_model *m, orc_data *d) {
       done = fdone;
     }
     if (done && !(m->iterations == 1 && niter == 0)) break;
-    slv_linesearch(m, d, &c, niter < ORC_TRACE_ITERS ? d->trace + 8 + 32 * niter : NULL,
-                   (fol && niter < ORC_TRACE_ITERS) ? fol + 8 + 32 * niter : NULL, report);
+    slv_linesearch(m, d, &c, niter < ORC_TRACE_ITERS ? d->trace + 8 + ORC_TRACE_REC * niter : NULL,
+                   (fol && niter < ORC_TRACE_ITERS) ? fol + 8 + ORC_TRACE_REC * niter : NULL, report);
     memcpy(prev_grad, c.grad, sizeof(real) * nv), memcpy(prev_Mgrad, c.Mgrad, sizeof(real) * nv);
     slv_update_constraint(m, d, &c);
     slv_update_gradient(m, d, &c);
@@ -1187,6 +1244,7 @@ void orc_solve(const orc_model *m, orc_data *d) {
 
 /* forward.forward [UPSTREAM] */
 void orc_forward(const orc_model *m, orc_data *d) {
+  d->follow_report[6] = 0, d->follow_report[7] = 0;
   orc_kinematics(m, d);
   orc_com_pos(m, d);
   orc_crb(m, d);

@@ -53,7 +53,7 @@ def test_reset_matches_oracle(env):
 
 def test_step_matches_oracle(env):
     """One control step (5 substeps + glue) against the oracles made to follow the product's solver decisions
-    (tests/parity.py): every env within max(1e-5 of the array's scale, 25 x the float32 oracle's own deviation on that
+    (tests/parity.py): every env within max(1e-5 of the array's scale, 50 x the float32 oracle's own deviation on that
     env), no quantiles; counters / done exact; rtrunk (computed from the OLD state) tight."""
     import parity as P
 
@@ -61,10 +61,8 @@ def test_step_matches_oracle(env):
     sf, noise, act = _inputs(B, seed=1)
     o64, o32 = H.make_oracle(env, "f64"), H.make_oracle(env, "f32")
     st, err, dev, rep, ost = P.control_step_follow(env, o64, o32, sf, noise, act)
-    viol = P.bound_violations(err, dev)
     print("\n[control step, 256 envs] " + ", ".join(f"{k}: max {v.max():.2e} median {np.median(v):.2e}" for k, v in err.items()))
-    for f, idx in viol.items():
-        assert len(idx) == 0, (f, idx[:8], err[f][idx[:8]], dev[f][idx[:8]])
+    P.check_control_step(err, dev, rep)
     assert np.median(err["qvel"]) < 1e-5 and np.median(err["qacc_warmstart"]) < 1e-5
     assert np.array_equal(st.done.cpu().numpy(), ost["done"].astype(np.float32))
     assert np.array_equal(st.info["cur_frame"].cpu().numpy(), ost["cur_frame"])

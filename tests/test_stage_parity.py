@@ -43,8 +43,8 @@ def _report(title, err, dev, viol):
                                        pytest.param("hip", 4096, id="hip-4096", marks=pytest.mark.gpu)])
 def test_single_substeps_match_oracle_at_1e5(backend, B):
     """(a) ONE physics substep at a time, five in a row, the oracles restarted from the product's own state each time:
-    every output of every env within max(1e-5 of the array's scale, 25 x the float32 oracle's own deviation on that
-    env); the solver decisions the oracles were made to follow must be legitimate (ties at rounding level)."""
+    every output of every env within max(1e-5 of the array's scale, 50 x the float32 oracle's own deviation on that
+    env), and over the batch no less accurate than the float32 oracle; the solver decisions the oracles were made to follow must be legitimate (ties at rounding level)."""
     env1 = _env(backend, B, n_frames=1)
     o64, o32 = H.make_oracle(env1, "f64"), H.make_oracle(env1, "f32")
     sf, noise, act = _inputs(B, seed=5)
@@ -54,6 +54,7 @@ def test_single_substeps_match_oracle_at_1e5(backend, B):
         print("   followed decisions:", P.assert_legitimate(rep))
         for f, idx in viol.items():
             assert len(idx) == 0, (k, f, idx[:8], err[f][idx[:8]], dev[f][idx[:8]])
+        P.assert_no_less_accurate_than_f32_oracle(err, dev)
 
 
 @pytest.mark.parametrize("backend,B", [pytest.param("hostsim", 24, id="hostsim-24"),
@@ -100,9 +101,21 @@ def test_glue_matches_oracle_on_the_products_own_state(backend, B):
         print(f"\n[{backend} glue, step {step}] " + ", ".join(f"{k} {v.max():.2e} (f32 oracle {dev[k].max():.2e})" for k, v in err.items()))
         assert flags["done_equal"] and flags["frames_equal"]
         assert err["obs"].max() < 1e-6 and err["traj"].max() < 2e-6
-        for name in err:  # 1e-6 of the scale, or 10 x the float32 oracle's own deviation (arccos near 1 in rquat)
-            bad = np.where(err[name] > np.maximum(2e-6, 10 * dev[name]))[0]
-            assert len(bad) == 0, (name, bad[:8], err[name][bad[:8]], dev[name][bad[:8]])
+        # Float32 conditioning of the reward terms (part of the reference's own float32 arithmetic): each is
+        # 0.01 exp(-k x), so the roundings of the exponent (k x up to ~20 for rapp = exp(-400 |d|)) come out as ~8 eps |k x|
+        # of relative error; rquat's exponent is arccos(2 (q.q_ref)^2 - 1) near 1, which turns ~24 eps of argument into
+        # 24 eps / sin(theta) of angle.  Everything else is held to 2e-6 of its scale.
+        eps = 6e-8
+        mt = {k: P.to_np(st.metrics[k]).astype(np.float64) for k in ("rcom", "rvel", "rquat", "rapp")}
+        expo = {k: -np.log(np.maximum(v / 0.01, 1e-30)) for k, v in mt.items()}
+        tol = {k: 2e-6 + 8 * eps * expo[k] * (v / max(float(v.max()), 1e-30)) for k, v in mt.items()}
+        tol["rquat"] = tol["rquat"] + 24 * eps / np.maximum(np.sin(np.minimum(expo["rquat"], 1.5)), 1e-4)
+        rmax = max(float(np.abs(P.to_np(st.reward)).max()), 1e-30)
+        tol["reward"] = 2e-6 + sum((tol[k] - 2e-6) * float(mt[k].max()) / rmax for k in mt)
+        for name in err:
+            t = tol.get(name, 2e-6)
+            bad = np.where(err[name] > t)[0]
+            assert len(bad) == 0, (name, bad[:8], err[name][bad[:8]], np.broadcast_to(t, err[name].shape)[bad[:8]])
 
 
 @pytest.mark.parametrize("backend,B", [pytest.param("hostsim", 32, id="hostsim-32"),
@@ -110,17 +123,37 @@ def test_glue_matches_oracle_on_the_products_own_state(backend, B):
                                        pytest.param("hip", 4096, id="hip-4096", marks=pytest.mark.gpu)])
 def test_control_step_matches_oracle_following_decisions(backend, B):
     """(d) The full control step (5 substeps in one launch): the oracles follow the product's solver decisions of every
-    substep; every env within max(1e-5, 25 x its own float32 sensitivity); the followed decisions legitimate."""
+    substep; every env within max(1e-5, 50 x its own float32 sensitivity); the followed decisions legitimate."""
     env = _env(backend, B)
     o64, o32 = H.make_oracle(env, "f64"), H.make_oracle(env, "f32")
     sf, noise, act = _inputs(B, seed=1)
-    st, err, dev, rep, ost = P.control_step_follow(env, o64, o32, sf, noise, act)
+    import os
+
+    st, err, dev, rep, ost = P.control_step_follow(env, o64, o32, sf, noise, act, dump_to=os.path.join(H.ROOT, "gpurun_out", f"control_step_{backend}_B{B}.npz") if backend == "hip" else None)
     viol = P.bound_violations(err, dev)
     _report(f"{backend} B={B} control step", err, dev, viol)
-    # (legitimacy of the decisions is asserted in the resynchronised single-substep test: here the two sides' states
-    # drift apart over the substeps, so a decision that was a tie for the product need not be one for the oracle)
     print("   followed decisions (informative):", P.legitimacy_summary(rep))
-    for f, idx in viol.items():
-        assert len(idx) == 0, (f, idx[:8], err[f][idx[:8]], dev[f][idx[:8]])
+    P.check_control_step(err, dev, rep)
     assert np.array_equal(P.to_np(st.done).astype(np.float64), ost["done"])
     assert np.array_equal(P.to_np(st.info["cur_frame"]), ost["cur_frame"])
+
+
+@pytest.mark.parametrize("backend,B", [pytest.param("hostsim", 16, id="hostsim-16"),
+                                       pytest.param("hip", 4096, id="hip-4096", marks=pytest.mark.gpu)])
+def test_fused_control_step_equals_five_single_substep_launches(backend, B):
+    """The control step is ONE launch that keeps the state on chip over its five substeps.  It must give, bit for bit, what
+    five launches of the single-substep configuration give (state through HBM in between) -- which ties the full control
+    step to the resynchronised single-substep comparison above with no tolerance in between."""
+    sf, noise, act = _inputs(B, seed=17)
+    env5, env1 = _env(backend, B), _env(backend, B, n_frames=1)
+    a = torch.from_numpy(act)
+    s5 = env5.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    s1 = env1.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    for _ in range(2):
+        s5 = env5.step(s5, a)
+        for _ in range(5):
+            s1 = env1.step(s1, a)
+        for k in ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xquat", "qfrc_actuator", "subtree_com_root"):
+            x5, x1 = getattr(s5.pipeline_state, k), getattr(s1.pipeline_state, k)
+            assert torch.equal(x5, x1), (k, float((x5 - x1).abs().max()))
+        assert torch.equal(s5.obs, s1.obs)

@@ -1292,6 +1292,18 @@ struct EnvWave {
     }
     VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
     VNL_SYNC();
+    if (trace) {  // debug trace: which rows exist (the pre-solver discrete decisions)
+      VNL_SERIAL {
+        for (int w = 0; w < 16; w++) {
+          int bits = 0;
+          for (int b = 0; b < 32; b++) {
+            const int r = 32 * w + b;
+            if (r < m.nefc && s[L.efc_D + r] != vreal(0.)) bits |= 1 << b;
+          }
+          trace[VNL_TRACE_ROWS + w] = bits;
+        }
+      }
+    }
   }
 
   // Q[k] = sum_{d<k} cdof_d * vec_d, k = 0 .. nv (6 floats each): a wave scan carried across the trips
@@ -1491,13 +1503,13 @@ struct EnvWave {
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
       if (tr) {
         const int n0 = ls_count_active(rows, a1[0]);
-        VNL_SERIAL { tr[4] = n0; }
+        VNL_SERIAL { tr[4] = n0, tr[24] = __builtin_bit_cast(int, (float)a1[0]); }
       }
       a1[0] = p0.alpha - p0.d0 / p0.d1;
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
       if (tr) {
         const int n1 = ls_count_active(rows, a1[0]);
-        VNL_SERIAL { tr[5] = n1; }
+        VNL_SERIAL { tr[5] = n1, tr[25] = __builtin_bit_cast(int, (float)a1[0]); }
       }
       if (tr) {
         const int first_lo = lo.d0 < p0.d0;
@@ -1528,6 +1540,8 @@ struct EnvWave {
           VNL_SERIAL {
             if (li < 6) {
               tr[6 + 3 * li] = c0, tr[7 + 3 * li] = c1, tr[8 + 3 * li] = c2;
+              tr[26 + 3 * li] = __builtin_bit_cast(int, (float)a3[0]), tr[27 + 3 * li] = __builtin_bit_cast(int, (float)a3[1]);
+              tr[28 + 3 * li] = __builtin_bit_cast(int, (float)a3[2]);
               tr[2] |= ((int)s1 | (int)s2 << 1 | (int)s3 << 2 | (int)s4 << 3) << (4 * li);
             }
             tr[1] = li + 1;
@@ -1563,7 +1577,7 @@ struct EnvWave {
     vreal cost_w = fresh().constraint_cost(L.jv) + vreal(0.5) * gw;
     bool use_warm = cost_w < cost_s;
     if (trace) {
-      VNL_FOR(k, VNL_TRACE_INTS) trace[k] = k == 0 ? (int)use_warm : 0;
+      VNL_FOR(k, VNL_TRACE_ROWS) trace[k] = k == 0 ? (int)use_warm : 0;
     }
     VNL_FOR(d, nv) {
       s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
@@ -1608,7 +1622,7 @@ struct EnvWave {
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(18);
-      int* tr = (trace && it < VNL_TRACE_ITERS) ? trace + 8 + 32 * it : nullptr;
+      int* tr = (trace && it < VNL_TRACE_ITERS) ? trace + 8 + VNL_TRACE_REC * it : nullptr;
       if (trace) {
         VNL_SYNC();  // (the zero fill above is by all lanes, the entries by lane 0)
         VNL_SERIAL { trace[1] = it + 1; }

@@ -18,13 +18,15 @@ typedef VNL_REAL vreal;
 #define VNL_GEOM_ELLIPSOID 4
 
 /* Debug trace of the DISCRETE decisions of one solver call (written only when vnl_env_debug is on; the test-side CPU
- * checker records the same layout): [0] warm start used, [1] iterations, then per iteration 32 ints:
+ * checker records the same layout): [0] warm start used, [1] iterations, then per iteration 64 ints:
  * [0] float bits of the accepted step length, [1] line-search iterations, [2] the four bracket-replacement decisions
  * of every line-search iteration (4 bits each), [3] pick (0 none, 1 lo, 2 hi), [4..24) rows active at every trial
  * step length (p0, first Newton point, then lo_next / hi_next / mid per line-search iteration); bit 24 of [2]: the
- * first Newton point became `lo`. */
+ * first Newton point became `lo`; [24..44) the float bits of those 20 trial step lengths. */
 #define VNL_TRACE_ITERS 8
-#define VNL_TRACE_INTS (8 + 32 * VNL_TRACE_ITERS)
+#define VNL_TRACE_REC 64 /* ints per iteration record */
+#define VNL_TRACE_ROWS (8 + VNL_TRACE_REC * VNL_TRACE_ITERS) /* then 16 ints: bit r set = constraint row r present (D != 0) */
+#define VNL_TRACE_INTS (VNL_TRACE_ROWS + 16)
 
 #define VNL_FAC_LINES 6 /* pivots per factorisation step (scratch lines in the dead CG vectors) */
 
