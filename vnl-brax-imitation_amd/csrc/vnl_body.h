@@ -256,6 +256,8 @@ struct EnvWave {
   VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * m.nbody; }
   VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * m.nbody; }
   VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * m.nv; }
+  // library-owned global scratch of this env: the second factor of a substep (factor_pair), nM + nv elements
+  VNL_HD vreal* fac2() const { return ev.fac2 + (size_t)e * (m.nM + m.nv); }
   VNL_HD V3 gpos3(int b) const {
     const vreal* x = gxpos() + 3 * b;
     return V3{x[0], x[1], x[2]};
@@ -882,7 +884,7 @@ struct EnvWave {
   // N only needs its own earlier entries (registers) and the ORIGINAL rows of its ancestors, so all
   // rows run at once without levels; the results are written back after one barrier.
   template <int NSET, int MAXD, int MAXD1 = MAXD>
-  VNL_HD void invert_rows() const {
+  VNL_HD void invert_rows(int LDb) const {
     auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
     // Sets are taken from the last to the first and written back one at a time: rows of a later
     // set are never ancestors of rows of an earlier one.
@@ -892,11 +894,11 @@ struct EnvWave {
       int a = (int)lane + q * VNL_LANES;
       bool ok = a < m.nv;
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
-      int own = L.LD + adr;
+      int own = LDb + adr;
       const vreal* pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
 #pragma unroll
       for (int u = 1; u < MAXD; u++)
-        if (u < qd(q)) pb[u] = s + L.LD + (u < d ? madr(anc_of(adr + u)) : 0);
+        if (u < qd(q)) pb[u] = s + LDb + (u < d ? madr(anc_of(adr + u)) : 0);
 #pragma unroll
       for (int t = 1; t < MAXD; t++) {
         if (t < qd(q) && vnl_wave_any(t <= d)) {
@@ -915,6 +917,152 @@ struct EnvWave {
         if (t < qd(q) && t <= d) s[own + t] = nn[t];
       VNL_SYNC();
     }
+  }
+
+  // The TWO factorisations of a substep in ONE pass: forward.euler's implicit damping needs M + h diag(damping), the
+  // solver needs M, both from the same qpos.  Their rows sit side by side in registers and go through the same
+  // scheduled elimination (one dependent chain of LDS round trips instead of two, the second system's updates fill the
+  // first one's waits); the mass matrix is built once.  System 1 ends in L.LD / L.dinv as factor_rows leaves it;
+  // system 2 (unit-lower rows scaled by 1/D, then 1/D) goes to this env's global scratch `g2` [nM + nv] and is
+  // brought back by euler() once the solver has released the pool.
+  // Which published pivots row a must absorb in which step is static per model: m.fac_match[a][step] (one bit per
+  // scratch line, host-made), read one step ahead -- no line headers, no per-step ancestor tests.
+  template <int NSET, int MAXD, int MAXD1 = MAXD>
+  VNL_HD void factor_pair(vreal h, vreal* g2) const {
+    static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
+    constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
+    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
+    constexpr int LW = MAXD + 4;  // [row numerators (MAXD) | 1/pivot | pad]
+    vreal r1[NSET][MAXD], r2[NSET][MAXD], d1[NSET], d2[NSET], inv2[NSET];
+    int dep[NSET], ftime[NSET], myline[NSET];
+    const unsigned char* mt[NSET];
+    const int sc = (L.Ma + 3) & ~3, sc2 = sc + VNL_FAC_LINES * LW;  // Ma .. tmp2 are dead while factorising
+    const int nsteps = m.fac_steps;
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      int a = (int)lane + q * VNL_LANES;
+      bool ok = a < m.nv;
+      int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
+      dep[q] = d;
+      d1[q] = ok ? s[L.LD + adr] : vreal(1.);
+      d2[q] = ok ? d1[q] + h * m.dof_damping[a] : vreal(1.);
+      inv2[q] = vreal(0.);
+#pragma unroll
+      for (int c = 0; c < MAXD; c++)
+        if (c < qd(q)) r1[q][c] = r2[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
+      myline[q] = ok ? (m.dof_fslot[a] & 0xff) : 0;
+      ftime[q] = ok ? m.dof_ftime[a] : -1;
+      mt[q] = m.fac_match + (size_t)(ok ? a : 0) * nsteps;
+    }
+    unsigned nxt[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; q++) nxt[q] = ((int)lane + q * VNL_LANES < m.nv && nsteps > 0) ? mt[q][0] : 0u;
+    VNL_SYNC();
+    VNL_PROF(7);
+    for (int step = 0; step < nsteps; step++) {
+      unsigned cur[NSET];
+#pragma unroll
+      for (int q = 0; q < NSET; q++) {
+        cur[q] = nxt[q];
+        nxt[q] = ((int)lane + q * VNL_LANES < m.nv && step + 1 < nsteps) ? mt[q][step + 1] : 0u;  // prefetch
+        if (ftime[q] == step) {
+          const int l1 = sc + myline[q] * LW, l2 = sc2 + myline[q] * LW, a = (int)lane + q * VNL_LANES;
+#pragma unroll
+          for (int c0 = 0; c0 < MAXD; c0 += CH) {
+            if (c0 < qd(q) && c0 < dep[q]) {
+#pragma unroll
+              for (int c = c0; c < c0 + CH; c += 4)
+                if (c < qd(q)) {
+                  st4a(s + l1 + c, r1[q][c], r1[q][c + 1], r1[q][c + 2], r1[q][c + 3]);
+                  st4a(s + l2 + c, r2[q][c], r2[q][c + 1], r2[q][c + 2], r2[q][c + 3]);
+                }
+            }
+          }
+          const vreal i1 = vnl_recip(d1[q]), i2 = vnl_recip(d2[q]);
+          s[l1 + MAXD] = i1, s[l2 + MAXD] = i2;
+          s[L.dinv + a] = i1;
+          inv2[q] = i2;
+        }
+      }
+      VNL_WAVE_FENCE();
+      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
+        bool more = false;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) more = more || cur[q] != 0u;
+        if (!vnl_wave_any(more)) break;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) {
+          if (cur[q] != 0u) {
+            const int k = __builtin_ctz(cur[q]);
+            cur[q] &= cur[q] - 1u;
+            const vreal* ln1 = s + sc + k * LW;
+            const vreal* ln2 = s + sc2 + k * LW;
+            // first column chunk fetched together with the pivot entries and 1/D: one LDS round trip, not two
+            // (entries past the row's depth are don't-cares: never published, never stored); unconditional reads of
+            // every chunk were measured slower (2.52 vs 2.44 ms)
+            R4 x1[CH / 4], x2[CH / 4];
+#pragma unroll
+            for (int c = 0; c < CH; c += 4) x1[c / 4] = ld4a(ln1 + c), x2[c / 4] = ld4a(ln2 + c);
+            const vreal raw1 = ln1[dep[q]], raw2 = ln2[dep[q]];
+            const vreal t1 = raw1 * ln1[MAXD], t2 = raw2 * ln2[MAXD];
+#pragma unroll
+            for (int c = 0; c < CH; c += 4) {
+              R4 x = x1[c / 4], y = x2[c / 4];
+              r1[q][c] -= t1 * x.x, r1[q][c + 1] -= t1 * x.y, r1[q][c + 2] -= t1 * x.z, r1[q][c + 3] -= t1 * x.w;
+              r2[q][c] -= t2 * y.x, r2[q][c + 1] -= t2 * y.y, r2[q][c + 2] -= t2 * y.z, r2[q][c + 3] -= t2 * y.w;
+            }
+#pragma unroll
+            for (int c0 = CH; c0 < MAXD; c0 += CH) {
+              if (c0 < qd(q) && c0 < dep[q]) {
+#pragma unroll
+                for (int c = c0; c < c0 + CH; c += 4) {
+                  if (c < qd(q)) {
+                    R4 x = ld4a(ln1 + c), y = ld4a(ln2 + c);
+                    r1[q][c] -= t1 * x.x, r1[q][c + 1] -= t1 * x.y, r1[q][c + 2] -= t1 * x.z, r1[q][c + 3] -= t1 * x.w;
+                    r2[q][c] -= t2 * y.x, r2[q][c + 1] -= t2 * y.y, r2[q][c + 2] -= t2 * y.z, r2[q][c + 3] -= t2 * y.w;
+                  }
+                }
+              }
+            }
+            d1[q] -= t1 * raw1, d2[q] -= t2 * raw2;
+          }
+        }
+      }
+      VNL_WAVE_FENCE();
+    }
+    VNL_SYNC();
+    VNL_PROF(8);
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      int a = (int)lane + q * VNL_LANES;
+      if (a < m.nv) {
+        int adr = madr(a), d = dep[q];
+        vreal di = s[L.dinv + a];
+        s[L.LD + adr] = d1[q];
+        g2[adr] = d2[q], g2[m.nM + a] = inv2[q];
+#pragma unroll
+        for (int c = 0; c < MAXD; c++)
+          if (c < qd(q) && c < d) s[L.LD + adr + d - c] = r1[q][c] * di, g2[adr + d - c] = r2[q][c] * inv2[q];
+      }
+    }
+    VNL_SYNC();
+    VNL_PROF(9);
+  }
+  // models whose two factorisations go through factor_pair (same conditions as the register route of factor(), plus
+  // room for the second set of scratch lines in the eight dead vectors Ma .. tmp2 and for the factor copy in the pool)
+  VNL_HD bool factor_pair_ok() const {
+    const int nv = m.nv, md = m.max_depth;
+    if (!m.eulerdamp || !m.fac_match) return false;
+    const int room = 8 * nv - 3 - 8 * VNL_FAC_LINES;
+    const bool regs = (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) ||
+                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16);
+    return regs && 2 * VNL_FAC_LINES * (md < 16 ? 16 : 36) <= room;
+  }
+  VNL_HD void factor_both(vreal h, vreal* g2) const {
+    const int nv = m.nv, md = m.max_depth;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_pair<VNL_ROWSETS_1, 16>(h, g2);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) factor_pair<VNL_ROWSETS_1, 36>(h, g2);
+    else factor_pair<VNL_ROWSETS_2, 36, 16>(h, g2);
   }
 
   VNL_HD void factor(bool with_loop = true) const {
@@ -941,18 +1089,20 @@ struct EnvWave {
     else return false;
     return true;
   }
-  VNL_HD void invert_factor() const {
+  // (LDb: where the factor sits -- L.LD, or the copy of the second factor that euler() brings into the pool)
+  VNL_HD void invert_factor(int LDb) const {
     const int nv = m.nv, md = m.max_depth;
-    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_rows<VNL_ROWSETS_1, 16>();
-    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_1, 36>();
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16) invert_rows<VNL_ROWSETS_2, 36, 16>();
-    else invert_factor_lds();
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_rows<VNL_ROWSETS_1, 16>(LDb);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_1, 36>(LDb);
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16) invert_rows<VNL_ROWSETS_2, 36, 16>(LDb);
+    else invert_factor_lds();  // (only ever reached with LDb == L.LD: factor_pair_ok() excludes these models)
   }
+  VNL_HD void invert_factor() const { invert_factor(L.LD); }
 
   // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
-  VNL_HD vreal row_dot(int adr, int dep, int in) const {
+  VNL_HD vreal row_dot(int adr, int dep, int in, int LDb) const {
     const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
-    const vreal* row = s + L.LD + adr;
+    const vreal* row = s + LDb + adr;
     vreal acc = vreal(0.);
     int t = 1;
     constexpr int W = VNL_CHAIN_WIDTH;  // independent index->value chains per trip: two LDS round trips per trip
@@ -992,21 +1142,21 @@ struct EnvWave {
   }
 
   // out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]   (A = strictly-lower part held in LD: L or L^-1)
-  VNL_HD void row_apply(int in, int out, bool scale_by_dinv) const {
+  VNL_HD void row_apply(int in, int out, bool scale_by_dinv, int LDb, int dinvb) const {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[in + i] + row_dot(adr, dep, in);
-      s[out + i] = scale_by_dinv ? acc * s[L.dinv + i] : acc;
+      vreal acc = s[in + i] + row_dot(adr, dep, in, LDb);
+      s[out + i] = scale_by_dinv ? acc * s[dinvb + i] : acc;
     }
     VNL_SYNC();
   }
   // out[a] = (in[a] + sum_{i in desc(a)} A(i, a) in[i]) (* or / D); descendants are the next ndesc dofs
-  VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/) const {
+  VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/, int LDb, int dinvb) const {
     VNL_FOR(a, m.nv) {
       int da = eadr(a) - madr(a), nd = ndesc(a);
       vreal acc = s[in + a];
       const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
-      const vreal* ld = s + L.LD - da;
+      const vreal* ld = s + LDb - da;
       int i = a + 1, iend = a + nd;
       constexpr int W = VNL_CHAIN_WIDTH;
       for (; i + W - 1 <= iend; i += W) {
@@ -1041,26 +1191,27 @@ struct EnvWave {
         }
         acc += p0 + p1;
       }
-      s[out + a] = dmode == 1 ? acc * s[L.dinv + a] : (dmode == 2 ? acc / s[L.dinv + a] : acc);
+      s[out + a] = dmode == 1 ? acc * s[dinvb + a] : (dmode == 2 ? acc / s[dinvb + a] : acc);
     }
     VNL_SYNC();
   }
 
   // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
-  VNL_HD void solve_inplace(int x) const {
-    col_apply(x, L.tmp2, 1);
-    row_apply(L.tmp2, x, false);
+  VNL_HD void solve_inplace(int x, int LDb, int dinvb) const {
+    col_apply(x, L.tmp2, 1, LDb, dinvb);
+    row_apply(L.tmp2, x, false, LDb, dinvb);
   }
+  VNL_HD void solve_inplace(int x) const { solve_inplace(x, L.LD, L.dinv); }
 
   // out = M v = L' D L v with the (not yet inverted) factor
   VNL_HD void mass_mul_factor(int vec, int out) const {
     VNL_FOR(i, m.nv) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[vec + i] + row_dot(adr, dep, vec);
+      vreal acc = s[vec + i] + row_dot(adr, dep, vec, L.LD);
       s[L.tmp2 + i] = acc / s[L.dinv + i];
     }
     VNL_SYNC();
-    col_apply(L.tmp2, out, 0);
+    col_apply(L.tmp2, out, 0, L.LD, L.dinv);
   }
 
   // ------------------------------------------------------------------ velocity
@@ -1720,7 +1871,8 @@ struct EnvWave {
     VNL_PROF(1);
     int cvel = fresh().bias_forces();
     fresh().mass_matrix(vreal(0.));
-    fresh().factor();
+    if (factor_pair_ok()) fresh().factor_both(m.dt, fac2());
+    else fresh().factor();
     fresh().mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
     VNL_PROF(10);
     fresh().invert_factor();
@@ -1773,7 +1925,17 @@ struct EnvWave {
     VNL_PROF(26);  // the tail of solve()
     VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
     VNL_SYNC();
-    if (m.eulerdamp) {
+    if (m.eulerdamp && factor_pair_ok()) {
+      // the factor of M + h diag(damping) was made next to M's by forward() (factor_pair): bring it into the pool
+      // (the constraint rows are dead now), invert it there and apply it
+      const vreal* g2 = fac2();
+      const int n2 = m.nM + m.nv;
+      VNL_FOR(k, n2) s[L.P + k] = g2[k];
+      VNL_SYNC();
+      fresh().invert_factor(L.P);
+      fresh().solve_inplace(L.tmp, L.P, L.P + m.nM);
+      VNL_PROF(27);
+    } else if (m.eulerdamp) {
       fresh().body_inertias(false);
       VNL_PROF(1);
       fresh().mass_matrix(m.dt);

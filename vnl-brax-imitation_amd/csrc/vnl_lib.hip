@@ -417,6 +417,15 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       d.fac_nleaf |= deep1 << 8;
     }
     UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
+    {  // fac_match[a][t]: the scratch lines whose pivot of step t lies strictly below row a (factor_pair absorbs them)
+      const int nst = d.fac_steps;
+      std::vector<unsigned char> match((size_t)nv * (nst > 0 ? nst : 1), 0);
+      for (int j = 0; j < nv; j++)
+        for (int a = par[j]; a >= 0; a = par[a]) match[(size_t)a * nst + ftime[j]] |= (unsigned char)(1u << (fslot[j] & 0xff));
+      const unsigned char* dp = nullptr;
+      if ((rc = upload<unsigned char, unsigned char>(env, match, &dp)) != VNL_OK) return rc;
+      d.fac_match = dp;
+    }
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
@@ -489,6 +498,7 @@ static void layout(vnl_env* env) {
   L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", imax(d.nM, 6 * (d.nv + 1) + 6 * (d.nbody + 1)))  /* also holds the dof / body prefix sums of bias_forces */, L.dinv = sec("qLDiagInv", d.nv);
   // solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul
   int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
+  if (d.eulerdamp) pool = imax(pool, d.nM + d.nv);  // euler() brings the second factor of the substep back into the pool
   L.P = sec("pool", pool);
   L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
   env->sections["efc_D"] = {L.efc_D, d.nefc}, env->sections["Jaref"] = {L.Jaref, d.nefc};
@@ -572,6 +582,12 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   UP(upload_raw<float>(env, es->angular_velocity, CT * 3, &e.angular_velocity))
   UP(upload_raw<float>(env, es->joints_velocity, CT * nj, &e.joints_velocity))
 #undef UP
+  {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t)num_envs * (d.nM + d.nv) * sizeof(vreal)));
+    env->allocs.push_back(p);
+    e.fac2 = (vreal*)p;
+  }
   layout(env);
   env->lds_bytes = (size_t)env->L.total * sizeof(vreal);
 #ifdef VNL_STAGE_KNOBS

@@ -59,6 +59,7 @@ struct DevModel {
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
   const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot; scratch line | one leaf under a << 8 | mask of all leaves under a << 16 */
+  const unsigned char* fac_match;    /* [nv][fac_steps]: bit k set = row a absorbs the pivot published in scratch line k in that step */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
   const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
   const vreal *dof_armature, *dof_damping;
@@ -76,6 +77,7 @@ struct DevEnv {
   vreal healthy_lo, healthy_hi, inv_term_threshold, body_err_mult;
   const int *body_idxs, *end_eff_idx, *app_body, *app_ref_col, *joint_cols;
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
+  vreal* fac2; /* library-owned scratch [num_envs][nM + nv]: the second factor of a substep (EnvWave::factor_pair) */
 };
 
 // caller-owned buffers, row-major [env][feature] (see include/vnl.h vnl_state)
