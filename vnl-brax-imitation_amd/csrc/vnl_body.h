@@ -50,8 +50,9 @@
 #define VNL_SERIAL if (lane == 0)
 #define VNL_SYNC() __syncthreads()
 #define VNL_LDS_DECL(name) extern __shared__ __align__(16) vreal name[]
-// Cross-lane sum with DPP (VALU-rate) instead of ds_bpermute: xor-butterfly inside each row of 16
-// lanes (quad_perm, row_half_mirror, row_mirror), then the four row totals through v_readlane.
+// Cross-lane sum with DPP (VALU-rate) instead of ds_bpermute: xor-butterfly inside each row of 16 lanes (quad_perm,
+// row_half_mirror, row_mirror: every lane then holds its row's total), the row totals combined by row_bcast:15 (rows 1, 3
+// take rows 0, 2) and row_bcast:31 (row 3 takes rows 0+1), the grand total read from lane 63: 6 DPP adds + 1 v_readlane.
 // Every lane returns the same value.
 VNL_HD float vnl_wave_sum(float x) {
 #define VNL_DPP_STEP(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
@@ -60,9 +61,9 @@ VNL_HD float vnl_wave_sum(float x) {
   VNL_DPP_STEP(0x141);  // row_half_mirror
   VNL_DPP_STEP(0x140);  // row_mirror
 #undef VNL_DPP_STEP
-  int xi = __builtin_bit_cast(int, x);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16)) +
-         __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));  // row_bcast:15
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
 // inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row
@@ -280,6 +281,9 @@ struct EnvWave {
   VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
   VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + c]; }
   // last dof on the path of contact c's body (== nv if the body hangs off the world without dofs)
+  // compact list of the constraint rows that exist (after the active-contact list and the two counters)
+  VNL_HD unsigned short* live_rows() const { return (unsigned short*)((int*)(s + L.act_list) + (m.ncon + 3) / 4 + 2); }
+  VNL_HD int num_live_rows() const { return ((const int*)(s + L.act_list))[(m.ncon + 3) / 4 + 1]; }
   VNL_HD int con_lastdof(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + m.ncon + c]; }
   // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
   VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
@@ -1442,6 +1446,18 @@ struct EnvWave {
       VNL_SERIAL { ((int*)(s + L.act_list))[(m.ncon + 3) / 4] = na; }
     }
     VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
+    {  // the rows that exist (D != 0: violated limits, the four pyramid rows of every active contact), in row order:
+       // typically a few dozen of the 303, so the line search keeps ONE row per lane (line_search<1, compact>)
+      unsigned short* lv = live_rows();
+      int nl = 0;
+      VNL_FOR(r, VNL_PAD_ITEMS(m.nefc)) {
+        const bool on = r < m.nefc && s[L.efc_D + (r < m.nefc ? r : 0)] != vreal(0.);
+        int pos;
+        VNL_RANK(on, nl, pos);
+        if (on && pos < VNL_LIVE_MAX) lv[pos] = (unsigned short)r;
+      }
+      VNL_SERIAL { ((int*)(s + L.act_list))[(m.ncon + 3) / 4 + 1] = nl; }
+    }
     VNL_SYNC();
     if (trace) {  // debug trace: which rows exist (the pre-solver discrete decisions)
       VNL_SERIAL {
@@ -1601,22 +1617,27 @@ struct EnvWave {
   };
   // debug trace only: rows of this lane that exist (D != 0) and are active at step length alpha, summed over the wave
   template <int RPL>
-  VNL_HD int ls_count_active(const LsRows<RPL>& R, vreal alpha) const {
+  VNL_HD int ls_count_active(const LsRows<RPL>& R, vreal alpha, bool compact) const {
     int n = 0;
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool live = r < m.nefc && s[L.efc_D + (r < m.nefc ? r : 0)] != vreal(0.);
+      if (compact) live = (int)lane < num_live_rows();
       n += VNL_COUNT(live && R.ja[j] + alpha * R.jv[j] < vreal(0.));
     }
     return n;
   }
   template <int RPL>
-  VNL_HD void ls_load(LsRows<RPL>& R) const {
+  VNL_HD void ls_load(LsRows<RPL>& R, bool compact) const {
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool ok = r < m.nefc;
+      if (compact) {  // (RPL == 1) lane l takes the l-th existing row
+        ok = (int)lane < num_live_rows();
+        r = ok ? (int)live_rows()[lane] : 0;
+      }
       vreal D = ok ? fabs(s[L.efc_D + r]) : vreal(0.);
       vreal ja = ok ? s[L.Jaref + r] : vreal(0.), jv = ok ? s[L.jv + r] : vreal(0.);
       R.ja[j] = ja, R.jv[j] = jv;
@@ -1645,21 +1666,21 @@ struct EnvWave {
   }
 
   // exact line search of solver._linesearch; returns the accepted step length (0 if no improvement)
-  template <int RPL>
+  template <int RPL, bool COMPACT = false>
   VNL_HD vreal line_search(vreal gauss, vreal qg1, vreal qg2, vreal gtol, int* tr /* debug trace of this iteration or null */) const {
       LsPoint p0, lo, hi;
       LsRows<RPL> rows;
-      ls_load(rows);
+      ls_load(rows, COMPACT);
       vreal a1[1] = {vreal(0.)};
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
       if (tr) {
-        const int n0 = ls_count_active(rows, a1[0]);
+        const int n0 = ls_count_active(rows, a1[0], COMPACT);
         VNL_SERIAL { tr[4] = n0, tr[24] = __builtin_bit_cast(int, (float)a1[0]); }
       }
       a1[0] = p0.alpha - p0.d0 / p0.d1;
       ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
       if (tr) {
-        const int n1 = ls_count_active(rows, a1[0]);
+        const int n1 = ls_count_active(rows, a1[0], COMPACT);
         VNL_SERIAL { tr[5] = n1, tr[25] = __builtin_bit_cast(int, (float)a1[0]); }
       }
       if (tr) {
@@ -1687,7 +1708,7 @@ struct EnvWave {
         if (s4) hi = p[2];
         swap = s1 || s2 || s3 || s4;
         if (tr) {
-          const int c0 = ls_count_active(rows, a3[0]), c1 = ls_count_active(rows, a3[1]), c2 = ls_count_active(rows, a3[2]);
+          const int c0 = ls_count_active(rows, a3[0], COMPACT), c1 = ls_count_active(rows, a3[1], COMPACT), c2 = ls_count_active(rows, a3[2], COMPACT);
           VNL_SERIAL {
             if (li < 6) {
               tr[6 + 3 * li] = c0, tr[7 + 3 * li] = c1, tr[8 + 3 * li] = c2;
@@ -1778,8 +1799,10 @@ struct EnvWave {
         VNL_SYNC();  // (the zero fill above is by all lanes, the entries by lane 0)
         VNL_SERIAL { trace[1] = it + 1; }
       }
-      vreal alpha = (m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
-                                              : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol, tr);
+      vreal alpha = (num_live_rows() <= (VNL_LANES < VNL_LIVE_MAX ? VNL_LANES : VNL_LIVE_MAX))
+                        ? fresh().template line_search<1, true>(gauss, qg1, qg2, gtol, tr)
+                        : ((m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
+                                                     : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol, tr));
       VNL_FOR(d, nv) {
         s[L.qacc + d] += alpha * s[L.search + d];
         s[L.Ma + d] += alpha * s[L.mv + d];
@@ -1893,7 +1916,7 @@ struct EnvWave {
         vreal a3[3] = {vreal(0.), vreal(1e-4), vreal(2e-4)};
         LsPoint p[3];
         LsRows<VNL_ROWS_SMALL> rows;
-        ls_load(rows);
+        ls_load(rows, false);
         ls_eval<3>(rows, a3, vreal(0.), vreal(0.), vreal(0.), p);
         if (p[0].cost == vreal(-1.)) s[L.tmp] = p[1].cost;  // keep the result alive
       } else if (m.dbg_stage == 9) {
@@ -1908,7 +1931,7 @@ struct EnvWave {
         if (c == vreal(-1.)) s[L.tmp] = c;
       } else if (m.dbg_stage == 13) {
         LsRows<VNL_ROWS_SMALL> rows;
-        ls_load(rows);
+        ls_load(rows, false);
         vreal a1[1] = {vreal(1e-4)};
         LsPoint p;
         ls_eval<1>(rows, a1, vreal(0.), vreal(0.), vreal(0.), &p);

@@ -511,7 +511,7 @@ static void layout(vnl_env* env) {
   L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
   L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
-  L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 4));
+  L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 8 + 2 * VNL_LIVE_MAX));  // active contacts | their count | existing rows: count, list
 #ifdef VNL_PROFILE
   o = (o + 1) & ~1;
   L.prof = sec("prof", 2 * (VNL_NPROF + 1));

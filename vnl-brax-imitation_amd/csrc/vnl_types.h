@@ -28,6 +28,7 @@ typedef VNL_REAL vreal;
 #define VNL_TRACE_ROWS (8 + VNL_TRACE_REC * VNL_TRACE_ITERS) /* then 16 ints: bit r set = constraint row r present (D != 0) */
 #define VNL_TRACE_INTS (VNL_TRACE_ROWS + 16)
 
+#define VNL_LIVE_MAX 64 /* constraint rows kept in the compact list of existing rows (line search, one per lane) */
 #define VNL_FAC_LINES 6 /* pivots per factorisation step (scratch lines in the dead CG vectors) */
 
 struct DevModel {
