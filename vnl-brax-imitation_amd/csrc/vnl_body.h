@@ -284,6 +284,18 @@ struct EnvWave {
   // compact list of the constraint rows that exist (after the active-contact list and the two counters)
   VNL_HD unsigned short* live_rows() const { return (unsigned short*)((int*)(s + L.act_list) + (m.ncon + 3) / 4 + 2); }
   VNL_HD int num_live_rows() const { return ((const int*)(s + L.act_list))[(m.ncon + 3) / 4 + 1]; }
+  // body(r) for every constraint row that exists -- through the compact list when it holds them all (the rows make_constraint
+  // masked out have D = 0 and never contribute to a cost, force or gradient, so their Jaref / jv need no upkeep)
+  template <class F>
+  VNL_HD void for_live_rows(F body) const {
+    const int nl = num_live_rows();
+    if (nl <= VNL_LIVE_MAX) {
+      const unsigned short* lv = live_rows();
+      VNL_FOR(l, nl) body((int)lv[l]);
+    } else {
+      VNL_FOR(r, m.nefc) body(r);
+    }
+  }
   VNL_HD int con_lastdof(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + m.ncon + c]; }
   // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
   VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
@@ -1505,10 +1517,12 @@ struct EnvWave {
   // scan, carried across the trips) serves every contact: twist = sum over runs of Q[end] - Q[begin].
   VNL_HD void jac_mul(int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    VNL_FOR(r, m.nlimit) {
-      vreal v = copysign(vreal(1.), s[L.efc_D + r]) * s[vec + m.lim_dof[r]];
-      s[out + r] = accumulate ? s[out + r] + v : v;
-    }
+    for_live_rows([&](int r) {
+      if (r < m.nlimit) {
+        vreal v = copysign(vreal(1.), s[L.efc_D + r]) * s[vec + m.lim_dof[r]];
+        s[out + r] = accumulate ? s[out + r] + v : v;
+      }
+    });
     const int Q = L.P + 3 * m.nefc;  // the contact-wrench area of constraint_force: dead here
     dof_prefix(vec, Q);
     const unsigned char* act = (const unsigned char*)(s + L.act_list);
@@ -1531,10 +1545,10 @@ struct EnvWave {
   // 0.5 * sum_r D Jaref^2 [Jaref<0]
   VNL_HD vreal constraint_cost(int jaref) const {
     vreal c = vreal(0.);
-    VNL_FOR(r, m.nefc) {
+    for_live_rows([&](int r) {
       vreal x = s[jaref + r];
       c += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
-    }
+    });
     return vreal(0.5) * vnl_wave_sum(c);
   }
 
@@ -1547,10 +1561,12 @@ struct EnvWave {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     int Wc = L.P + 3 * m.nefc;  // after efc_D | Jaref | jv
     vreal cost = vreal(0.);
-    VNL_FOR(r, m.nlimit) {
-      vreal x = s[L.Jaref + r];
-      cost += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
-    }
+    for_live_rows([&](int r) {
+      if (r < m.nlimit) {
+        vreal x = s[L.Jaref + r];
+        cost += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
+      }
+    });
     {
       // Contacts are in body order and the subtree of a body is a contiguous body range, so the contacts under a
       // dof are ONE range [c0, c1) (host table): one lane per contact forms its wrench (zero if inactive), a wave
@@ -1741,7 +1757,7 @@ struct EnvWave {
     VNL_FOR(d, nv) s[L.tmp + d] = s[L.qacc + d] - s[L.qacc_smooth + d];
     VNL_SYNC();
     fresh().jac_mul(L.tmp, L.jv, false);  // J (warm - smooth)
-    VNL_FOR(r, ne) s[L.jv + r] += s[L.Jaref + r];  // Jaref(warm)
+    for_live_rows([&](int r) { s[L.jv + r] += s[L.Jaref + r]; });  // Jaref(warm)
     vreal gw = vreal(0.);
     VNL_FOR(d, nv) gw += (s[L.mv + d] - s[L.smooth + d]) * s[L.tmp + d];
     gw = vnl_wave_sum(gw);
@@ -1755,9 +1771,7 @@ struct EnvWave {
       s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
       s[L.Ma + d] = use_warm ? s[L.mv + d] : s[L.smooth + d];
     }
-    if (use_warm) {
-      VNL_FOR(r, ne) s[L.Jaref + r] = s[L.jv + r];
-    }
+    if (use_warm) for_live_rows([&](int r) { s[L.Jaref + r] = s[L.jv + r]; });
     VNL_SYNC();
     VNL_PROF(14);
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
@@ -1808,7 +1822,7 @@ struct EnvWave {
         s[L.Ma + d] += alpha * s[L.mv + d];
       }
       VNL_PROF(19);
-      VNL_FOR(r, ne) s[L.Jaref + r] += alpha * s[L.jv + r];
+      for_live_rows([&](int r) { s[L.Jaref + r] += alpha * s[L.jv + r]; });
       VNL_SYNC();
       VNL_PROF(20);
       // ---- constraint + gradient update
