@@ -245,6 +245,44 @@ int vnl_adam_step(float* params, const float* grads, float* mu, float* nu, const
                   double lr, double b1, double b2, double eps, void* stream); /* hyper-parameters as the Python doubles they are:
                   1 - b2 is formed in double before the cast to float32, as optax does */
 
+/* ---- PPO minibatch step, forward AND backward: the gradient of compute_ppo_intention_loss (reference
+ * ppo_imitation/intention_losses.py:91-202) w.r.t. the policy and value parameters, i.e. what jax.grad computes inside
+ * brax's gradient_update_fn for ppo_imitation/train.py:255-268.  Networks: the intention policy
+ * (intention_policy_network.py:20-105; encoder / decoder of Dense -> ReLU -> LayerNorm, heads fc2_mean / fc2_logvar,
+ * z = mean + eps exp(logvar / 2), decoder on [z | normalised obs], last decoder layer linear) and the value MLP
+ * (ppo_networks.py:114-118, swish, scalar output).  `params` / `grads`: flat float32 [policy | value] in the layout of
+ * INTEGRATION.md (Flax tensor order); grads is overwritten.  Minibatch arrays are time-major (index t*B + b).
+ * Everything is enqueued on `stream`; no host synchronisation (capturable in a hipGraph). */
+typedef struct vnl_ppo_net_spec {
+  int32_t traj_size, obs_size, action_size, latent_size;
+  int32_t num_encoder_layers, num_decoder_layers /* incl. the output layer of 2*action_size */, num_value_layers /* hidden */;
+  int32_t encoder_layers[8], decoder_layers[8], value_layers[8];
+} vnl_ppo_net_spec;
+typedef struct vnl_ppo_batch {
+  const float *traj;          /* [T*B][traj_size]   Transition.extras.state_extras.traj */
+  const float *obs;           /* [T*B][obs_size]    Transition.observation (raw, not normalised) */
+  const float *next_obs_last; /* [B][obs_size]      Transition.next_observation[-1] (bootstrap) */
+  const float *raw_action, *behaviour_log_prob, *reward, *truncation, *discount;
+  const float *eps_latent;    /* [T*B][latent]  N(0,1) draws of the reparameterisation */
+  const float *eps_entropy;   /* [T*B][act]     N(0,1) draws of the entropy estimate */
+  const float *obs_mean, *obs_std; /* [obs_size] running-statistics normaliser, or both NULL (identity) */
+} vnl_ppo_batch;
+typedef struct vnl_ppo_hparams {
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon, kl_weight, min_std, var_scale;
+  int32_t normalize_advantage, pad_;
+} vnl_ppo_hparams;
+typedef struct vnl_ppo_update vnl_ppo_update;
+int vnl_ppo_update_create(const vnl_ppo_net_spec*, int32_t T, int32_t B, int32_t device, vnl_ppo_update** out);
+void vnl_ppo_update_destroy(vnl_ppo_update*);
+int64_t vnl_ppo_update_num_params(const vnl_ppo_update*);
+/* device pointer of an intermediate of the LAST vnl_ppo_minibatch_grad call (valid until the next one; read it on the same
+ * stream): "vs", "advantages" [T*B], "values" [T*B + B] (baseline then bootstrap), "logits" [T*B][2 act],
+ * "latent_mean", "latent_logvar" [T*B][latent] */
+int vnl_ppo_update_buffer(const vnl_ppo_update*, const char* name, float** dev_ptr, int64_t* count);
+/* metrics [8] as vnl_ppo_head */
+int vnl_ppo_minibatch_grad(vnl_ppo_update*, const float* params, const vnl_ppo_batch*, const vnl_ppo_hparams*, float* grads,
+                           float* metrics, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

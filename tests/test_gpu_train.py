@@ -12,17 +12,17 @@ from vnl_brax_imitation_amd.ppo_imitation import train as ppo
 pytestmark = pytest.mark.gpu
 
 
-def _run(capture: bool):
+def _run(capture: bool, backend: str = "auto", steps: int = 3):
     dev = torch.device("cuda:0")
     env = RodentTracking(H.reference_clip(), num_envs=64, device=dev, **H.env_kwargs())
     nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=60,
                            encoder_layer_sizes=(128, 128), decoder_layer_sizes=(128, 128))
     log = []
     _, (norm, flat), _ = ppo.train(
-        environment=env, num_timesteps=3 * 64 * 5, episode_length=150, num_envs=64, learning_rate=1e-3,
+        environment=env, num_timesteps=steps * 64 * 5, episode_length=150, num_envs=64, learning_rate=1e-3,
         entropy_cost=1e-2, discounting=0.95, unroll_length=5, batch_size=16, num_minibatches=4,
         num_updates_per_batch=2, num_evals=1, normalize_observations=True, network_factory=nf, num_eval_envs=0,
-        eval_env=None, seed=3, capture_graph=capture, progress_fn=lambda s, m: log.append(m))
+        eval_env=None, seed=3, capture_graph=capture, update_backend=backend, progress_fn=lambda s, m: log.append(m))
     return norm, flat, log[-1], ppo.train.last_training_state
 
 
@@ -37,6 +37,20 @@ def test_graph_capture_matches_eager():
     for k in ("training/total_loss", "training/v_loss", "training/policy_loss", "training/kl_loss_intention"):
         assert abs(m0[k] - m1[k]) <= 1e-5 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
     assert torch.isfinite(f1).all()
+
+
+def test_hand_written_update_trains_like_the_autograd_update():
+    """The same short training run with the hand-written forward + backward (vnl_ppo_minibatch_grad) and with torch
+    autograd through the op-by-op loss: ONE training step (the same rollout: later ones would differ, the policies no
+    longer being bit-identical), 8 Adam steps on it; parameters and losses must agree."""
+    n0, f0, m0, ts0 = _run(True, "hip", steps=1)
+    n1, f1, m1, ts1 = _run(True, "torch", steps=1)
+    assert torch.equal(n0.mean, n1.mean)
+    d = float((ts0.params - ts1.params).abs().max())
+    print(f"\n[hip vs torch update, 8 Adam steps] max |param difference| {d:.2e} (lr 1e-3)")
+    assert d < 5e-5, d  # Adam turns a 1e-6 relative gradient difference into at most ~lr of parameter difference per step
+    for k in ("training/total_loss", "training/v_loss", "training/policy_loss", "training/kl_loss_intention"):
+        assert abs(m0[k] - m1[k]) <= 1e-4 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
 
 
 def test_training_with_evaluation_on_gpu():

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--updates", type=int, default=16)
+    ap.add_argument("--backend", default="auto", help="minibatch step: hip (hand-written fwd+bwd) | torch (autograd) | auto")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank "
                     "(exercises the data-parallel code path: eager all-reduce + Adam between graph replays)")
     args = ap.parse_args()
@@ -56,12 +57,12 @@ def main():
               discounting=c["discounting"], unroll_length=unroll, batch_size=batch, num_minibatches=nmb,
               num_updates_per_batch=args.updates, num_evals=1, normalize_observations=True, network_factory=nf,
               num_eval_envs=0, eval_env=None, kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"],
-              progress_fn=lambda s, m: log.append((s, m)))
+              update_backend=args.backend, progress_fn=lambda s, m: log.append((s, m)))
     if int(os.environ.get("RANK", "0")) == 0:
         s, m = log[-1]
         print(json.dumps({"env_steps": s, "training/sps": m["training/sps"], "wall_s": time.time() - t0,
                           "total_loss": m["training/total_loss"], "v_loss": m["training/v_loss"], "n_gpus": world,
-                          "steps": args.steps, "updates_per_batch": args.updates}))
+                          "steps": args.steps, "updates_per_batch": args.updates, "backend": args.backend}))
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 

@@ -109,11 +109,31 @@ class PPOHeadArgs(C.Structure):  # include/vnl.h: vnl_ppo_head_args
 
 PPO_HEAD_WORKSPACE_FLOATS = 4 + 4 * 256
 
+
+class PPONetSpec(C.Structure):  # include/vnl.h: vnl_ppo_net_spec
+    _fields_ = [(n, C.c_int32) for n in ("traj_size", "obs_size", "action_size", "latent_size", "num_encoder_layers",
+                                          "num_decoder_layers", "num_value_layers")] + \
+               [("encoder_layers", C.c_int32 * 8), ("decoder_layers", C.c_int32 * 8), ("value_layers", C.c_int32 * 8)]
+
+
+class PPOBatch(C.Structure):  # include/vnl.h: vnl_ppo_batch
+    _fields_ = [(n, C.c_void_p) for n in ("traj", "obs", "next_obs_last", "raw_action", "behaviour_log_prob", "reward",
+                                          "truncation", "discount", "eps_latent", "eps_entropy", "obs_mean", "obs_std")]
+
+
+class PPOHParams(C.Structure):  # include/vnl.h: vnl_ppo_hparams
+    _fields_ = [(n, C.c_float) for n in ("entropy_cost", "discounting", "reward_scaling", "gae_lambda",
+                                         "clipping_epsilon", "kl_weight", "min_std", "var_scale")] + \
+               [("normalize_advantage", C.c_int32), ("pad_", C.c_int32)]
+
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
     "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
     "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step", "vnl_gather_rows",
+    "vnl_ppo_update_create", "vnl_ppo_update_destroy", "vnl_ppo_update_num_params", "vnl_ppo_update_buffer",
+    "vnl_ppo_minibatch_grad",
 )
+_HIP_ONLY = ("vnl_policy_", "vnl_ppo_update_", "vnl_ppo_minibatch_")  # not in the test-only host simulation
 
 
 class VnlError(RuntimeError):
@@ -139,6 +159,14 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_ppo_head.argtypes = [C.POINTER(PPOHeadArgs), vp, vp]
     lib.vnl_gather_rows.argtypes = [C.POINTER(GatherDesc), vp]
     lib.vnl_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int64] + [C.c_double] * 4 + [vp]
+    if hasattr(lib, "vnl_ppo_update_create"):
+        lib.vnl_ppo_update_create.argtypes = [C.POINTER(PPONetSpec), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        lib.vnl_ppo_update_destroy.argtypes = [vp]
+        lib.vnl_ppo_update_destroy.restype = None
+        lib.vnl_ppo_update_num_params.argtypes = [vp]
+        lib.vnl_ppo_update_num_params.restype = C.c_int64
+        lib.vnl_ppo_update_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int64)]
+        lib.vnl_ppo_minibatch_grad.argtypes = [vp, vp, C.POINTER(PPOBatch), C.POINTER(PPOHParams), vp, vp, vp]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
         lib.vnl_policy_destroy.argtypes = [vp]
@@ -162,7 +190,7 @@ def load_library(path: str | None = None, env_only: bool = False) -> C.CDLL:
                 f"HIP extension not found at {path}. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the rollout.")
         lib = C.CDLL(path)
-        missing = [s for s in EXPORTS if not hasattr(lib, s) and not (env_only and s.startswith("vnl_policy_"))]
+        missing = [s for s in EXPORTS if not hasattr(lib, s) and not (env_only and s.startswith(_HIP_ONLY))]
         if missing:
             raise VnlError(f"{path} lacks symbols {missing}")
         _cache[path] = _declare(lib)

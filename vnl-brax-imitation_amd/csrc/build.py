@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["vnl_lib.hip", "vnl_policy.hip"]
+SOURCES = ["vnl_lib.hip", "vnl_policy.hip", "vnl_ppo.hip"]
 DEPS = SOURCES + ["vnl_body.h", "vnl_types.h", "../../include/vnl.h"]
 OUT = os.path.join(HERE, "libvnl.so")
 

@@ -122,6 +122,7 @@ def train(
     reset_info_on_autoreset: bool = False,
     capture_graph: Optional[bool] = None,
     restore_from: Optional[str] = None,
+    update_backend: str = "auto",
 ):
     """PPO training (train.py:62-491).
 
@@ -131,6 +132,11 @@ def train(
 
     `restore_from`: a file written by `checkpoint.save_params` (full training state if it holds one, else
     the inference pair only) -- the reference cannot resume.
+
+    `update_backend`: "hip" = the hand-written forward + backward of the minibatch step (csrc/vnl_ppo.hip through
+    vnl_ppo_minibatch_grad: fp32 MFMA GEMMs with fused epilogues, gradients straight into the flat buffer), "torch" =
+    autograd through the op-by-op loss (hipBLASLt), "auto" = hip on a HIP device for the networks of
+    make_intention_ppo_networks.
 
     `capture_graph` (default: on for HIP devices): the minibatch step (gather -> loss -> backward
     [-> Adam when single-GPU]) is captured once into a hipGraph and replayed -- the eager step is
@@ -204,8 +210,47 @@ def train(
         discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
         clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage, kl_weight=kl_weight)
 
+    from . import hip_update
+
+    assert update_backend in ("auto", "hip", "torch")
+    use_hip_update = update_backend == "hip" or (update_backend == "auto" and device.type == "cuda" and
+                                                  hip_update.supported(ppo_network))
+    hip_upd: Dict[Any, Any] = {}
+    _METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "entropy_loss", "kl_loss_intention", "explained_variance")
+
+    def hip_grad(data_tm: acting.Transition, normalizer_params, noise) -> Metrics:
+        """d loss / d flat -> flat_grad by the hand-written kernels; `data_tm` time-major [T, mb, ...]."""
+        T, mb = data_tm.reward.shape[:2]
+        if (T, mb) not in hip_upd:
+            hip_upd[(T, mb)] = hip_update.HipPPOUpdate(
+                ppo_network, T, mb, device, entropy_cost=entropy_cost, discounting=discounting, reward_scaling=reward_scaling,
+                gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage,
+                kl_weight=kl_weight)
+        upd = hip_upd[(T, mb)]
+        mt = upd.grad(training_state.params, normalizer_params, data_tm, noise, flat_grad)
+        metrics = {k: mt[i] for i, k in enumerate(_METRIC_KEYS)}
+        with torch.no_grad():
+            if T * 2 <= 256:
+                vs = upd.buffer("vs").view(T, mb)
+                metrics["prediction_corr"] = ppo_losses._corrcoef(torch.cat([vs, data_tm.reward * reward_scaling], dim=0)).mean()
+            else:
+                metrics["prediction_corr"] = torch.zeros((), device=device)
+        return metrics
+
     def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
         """train.py:255-268 + brax gradient_update_fn: grad, all-reduce(mean), adam."""
+        if use_hip_update:
+            tm = data.map(lambda x: x.transpose(0, 1).contiguous())
+            T, mb = tm.reward.shape[:2]
+            noise = {"latent": torch.randn((T, mb, ppo_network.policy_module.latents), generator=g_dev, device=device),
+                     "entropy": torch.randn((T, mb, ppo_network.parametric_action_distribution.event_size), generator=g_dev,
+                                            device=device)}
+            metrics = hip_grad(tm, normalizer_params, noise)
+            if dist is not None:
+                dist.all_reduce(flat_grad)  # C1: one flat buffer
+                flat_grad.div_(world)
+            optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
+            return metrics
         leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
         loss, metrics = loss_fn(leaf_params, normalizer_params, data, g_dev)
         loss.backward()
@@ -258,10 +303,13 @@ def train(
         def body():
             _lib.check(lib, lib.vnl_gather_rows(C.byref(gd), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
             mbd = g["mb"]
-            leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
-            loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"], time_major=True)
-            loss.backward()
-            leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
+            if use_hip_update:
+                metrics = hip_grad(mbd, g["norm"], g["noise"])
+            else:
+                leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
+                loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"], time_major=True)
+                loss.backward()
+                leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
             if dist is None:
                 optimizer.update(flat_grad, training_state.optimizer_state, p)
             return metrics
