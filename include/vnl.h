@@ -87,7 +87,16 @@ typedef struct vnl_envspec {
   const float* velocity;         /* (C,T,3) */
   const float* angular_velocity; /* (C,T,3) */
   const float* joints_velocity;  /* (C,T,nq-7) */
+  /* Which tracking env's glue.  0 = RodentTracking (envs/rodent.py:178-316).  HumanoidTracking (envs/humanoid.py:185-311)
+   * = VNL_ENV_REWARD_OLD_STATE | VNL_ENV_TERM_MEAN | VNL_ENV_NO_RAPP | VNL_ENV_OBS_QPOS_QVEL with done_threshold 0.5. */
+  int32_t flags;
+  float done_threshold;          /* done when the UNSCALED rtrunk is below it: 0 (rodent.py:213), 0.5 (humanoid.py:199) */
+  const float* center_of_mass;   /* (C,T,3) reference for rcom (humanoid.py:273), or NULL: body_positions[com_ref_col] (rodent.py:279) */
 } vnl_envspec;
+#define VNL_ENV_REWARD_OLD_STATE 1 /* reward terms from the state BEFORE the step (humanoid.py:195: _calculate_reward(state, ..)) */
+#define VNL_ENV_TERM_MEAN 2        /* termination error = means of |.| (humanoid.py:256-260), not the matrix-1 / L1 norms */
+#define VNL_ENV_NO_RAPP 4          /* no appendage reward term */
+#define VNL_ENV_OBS_QPOS_QVEL 8    /* observation = [qpos, qvel] only (humanoid.py:354-368) */
 
 /* Caller-owned device buffers, row-major [num_envs][count]. */
 typedef struct vnl_state {

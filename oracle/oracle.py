@@ -43,13 +43,15 @@ class EnvSpec(C.Structure):
         ("healthy_z_hi", C.c_double),
         ("termination_threshold", C.c_double),
         ("body_error_multiplier", C.c_double),
+        ("flags", C.c_int),
+        ("done_threshold", C.c_double),
     ]
 
 
 class _Clip(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_float)) for n in
                 ("position", "quaternion", "joints", "body_positions", "velocity", "angular_velocity",
-                 "joints_velocity")]
+                 "joints_velocity", "center_of_mass")]
 
 
 _STATE_F = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xmat1", "com1", "qfrc_actuator", "obs", "traj",
@@ -68,6 +70,7 @@ def make_envspec(spec: dict) -> EnvSpec:
         setattr(e, k, int(spec[k]))
     for k in ("healthy_z_lo", "healthy_z_hi", "termination_threshold", "body_error_multiplier"):
         setattr(e, k, float(spec[k]))
+    e.flags, e.done_threshold = int(spec.get("flags", 0)), float(spec.get("done_threshold", 0.0))
     for k in ("body_idxs", "end_eff_idx", "app_body", "app_ref_col", "joint_cols"):
         arr = getattr(e, k)
         for i, v in enumerate(spec[k]):
@@ -97,6 +100,8 @@ class Oracle:
             getattr(L, "orc_" + fn).restype = None
         L.orc_env_reset.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
                                     C.c_void_p, C.POINTER(_State)]
+        L.orc_env_reset_follow.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
+                                           C.c_void_p, C.POINTER(_State), C.c_void_p, C.c_void_p]
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
                                    C.POINTER(_State)]
         L.orc_env_step_trace.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
@@ -104,7 +109,7 @@ class Oracle:
         L.orc_env_step_follow.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
                                           C.POINTER(_State), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_glue.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p, C.c_void_p,
-                                   C.POINTER(_State)]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_State)]
         L.orc_set_option.argtypes = [C.c_char_p, C.c_int]
         L.orc_get_option.argtypes = [C.c_char_p]
         L.orc_solver_trace.restype = C.POINTER(C.c_int)
@@ -164,9 +169,12 @@ class Oracle:
         self._clip_arrays = {k: np.ascontiguousarray(clip[k], dtype=np.float32) for k in
                              ("position", "quaternion", "joints", "body_positions", "velocity", "angular_velocity",
                               "joints_velocity")}
-        self._clip = _Clip(*[self._clip_arrays[k].ctypes.data_as(C.POINTER(C.c_float)) for k, _ in _Clip._fields_])
+        if clip.get("center_of_mass") is not None:
+            self._clip_arrays["center_of_mass"] = np.ascontiguousarray(clip["center_of_mass"], dtype=np.float32)
+        self._clip = _Clip(*[self._clip_arrays[k].ctypes.data_as(C.POINTER(C.c_float)) if k in self._clip_arrays else None
+                             for k, _ in _Clip._fields_])
         s = self.spec
-        self.obs_size = nq + 2 * nv + 3 * s.nee
+        self.obs_size = nq + nv if (s.flags & 8) else nq + 2 * nv + 3 * s.nee
         self.traj_size = s.ref_len * (3 * s.napp + 6 * s.nb + 3 + s.njc)
 
     def new_state(self, B: int) -> dict:
@@ -185,16 +193,24 @@ class Oracle:
         args += [st["cur_frame"].ctypes.data, st["sub_clip_frame"].ctypes.data, st["termination_error"].ctypes.data]
         return _State(*args)
 
-    def env_reset(self, start_frame: np.ndarray, noise: np.ndarray) -> dict:
+    def env_reset(self, start_frame: np.ndarray, noise: np.ndarray, follow: np.ndarray = None):
+        """-> state; with `follow` (another implementation's reset traces [B][n_frames][trace_ints]) -> (state, report)."""
         B = len(start_frame)
         st = self.new_state(B)
         sf = np.ascontiguousarray(start_frame, dtype=np.int32)
         nz = np.ascontiguousarray(noise, dtype=self.real)
         cs = self._cstate(st)
-        rc = self.lib.orc_env_reset(self.model, C.byref(self.spec), C.byref(self._clip), B, sf.ctypes.data,
-                                    nz.ctypes.data, C.byref(cs))
+        if follow is None:
+            rc = self.lib.orc_env_reset(self.model, C.byref(self.spec), C.byref(self._clip), B, sf.ctypes.data,
+                                        nz.ctypes.data, C.byref(cs))
+            assert rc == 0
+            return st
+        f = np.ascontiguousarray(follow, dtype=np.int32)
+        rep = np.zeros((B, 12), dtype=self.real)
+        rc = self.lib.orc_env_reset_follow(self.model, C.byref(self.spec), C.byref(self._clip), B, sf.ctypes.data,
+                                           nz.ctypes.data, C.byref(cs), f.ctypes.data, rep.ctypes.data)
         assert rc == 0
-        return st
+        return st, rep
 
     def env_step(self, st: dict, action: np.ndarray, trace: bool = False):
         """In-place on `st` (like the product's step); returns st, or (st, trace[B][n_frames][trace_ints])."""
@@ -222,7 +238,8 @@ class Oracle:
         assert rc == 0
         return st, tr, rep
 
-    def env_glue(self, st: dict, old_qpos: np.ndarray, old_xpos: np.ndarray) -> dict:
+    def env_glue(self, st: dict, old_qpos: np.ndarray, old_xpos: np.ndarray, old_qvel=None, old_com1=None,
+                 old_qfrc=None) -> dict:
         """rodent.py:183-239 on a caller-supplied NEW pipeline state: `st` holds the new qpos / qvel / act /
         qacc_warmstart / xpos / xmat1 / com1 / qfrc_actuator and the OLD frame counters; fills obs / traj / reward /
         done / metrics / termination_error in place and advances the counters."""
@@ -230,7 +247,8 @@ class Oracle:
         oq = np.ascontiguousarray(old_qpos, dtype=self.real)
         ox = np.ascontiguousarray(old_xpos, dtype=self.real).reshape(B, -1)
         cs = self._cstate(st)
-        rc = self.lib.orc_env_glue(self.model, C.byref(self.spec), C.byref(self._clip), B, oq.ctypes.data,
-                                   ox.ctypes.data, C.byref(cs))
+        extra = [None if x is None else np.ascontiguousarray(x, dtype=self.real) for x in (old_qvel, old_com1, old_qfrc)]
+        rc = self.lib.orc_env_glue(self.model, C.byref(self.spec), C.byref(self._clip), B, oq.ctypes.data, ox.ctypes.data,
+                                   *[None if x is None else x.ctypes.data for x in extra], C.byref(cs))
         assert rc == 0
         return st

@@ -1314,10 +1314,17 @@ typedef struct orc_envspec {
   int com_ref_col;     /* _com_idx applied to the nb-wide clip axis, clamped (quirk C.4) */
   int joint_cols[128]; /* _joint_idxs applied to the (nq-7)-wide joints axis, clamped (quirk C.5) */
   double healthy_z_lo, healthy_z_hi, termination_threshold, body_error_multiplier;
+  int flags;             /* ENV_* below: RodentTracking (0) or HumanoidTracking-style glue */
+  double done_threshold; /* done when the UNSCALED rtrunk is below it (rodent.py:213: 0; humanoid.py:199: 0.5) */
 } orc_envspec;
+#define ENV_REWARD_OLD_STATE 1 /* humanoid.py:195: _calculate_reward(state, action) uses the state BEFORE the step */
+#define ENV_TERM_MEAN 2        /* humanoid.py:256-260: means of |.| instead of the matrix-1 / L1 norms */
+#define ENV_NO_RAPP 4
+#define ENV_OBS_QPOS_QVEL 8    /* humanoid.py:354-368 */
 
 typedef struct orc_clip {
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
+  const float *center_of_mass; /* (T,3) or NULL: reference of rcom (humanoid.py:273) else body_positions[com_ref_col] */
 } orc_clip;
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -1334,6 +1341,7 @@ static real env_termination(const orc_model *m, const orc_envspec *e, const orc_
       col[i] += RFABS((real)c->body_positions[(f * e->nb + k) * 3 + i] - xpos[3 * e->body_idxs[k] + i]);
   real eb = col[0] > col[1] ? col[0] : col[1];
   eb = eb > col[2] ? eb : col[2];
+  if (e->flags & ENV_TERM_MEAN) eb = (col[0] + col[1] + col[2]) / (real)(3 * e->nb), ej = ej / (real)nj;
   real err = (real)0.5 * (real)e->body_error_multiplier * eb + (real)0.5 * ej;
   return 1 - err / (real)e->termination_threshold;
 }
@@ -1343,6 +1351,7 @@ static void env_obs(const orc_model *m, const orc_envspec *e, const orc_data *d,
   int k = 0;
   for (int i = 0; i < m->nq; i++) obs[k++] = d->qpos[i];
   for (int i = 0; i < m->nv; i++) obs[k++] = d->qvel[i];
+  if (e->flags & ENV_OBS_QPOS_QVEL) return;
   for (int i = 0; i < m->nv; i++) obs[k++] = d->qfrc_actuator[i];
   for (int j = 0; j < e->nee; j++)
     for (int i = 0; i < 3; i++) obs[k++] = d->xpos[3 * e->end_eff_idx[j] + i];
@@ -1419,12 +1428,16 @@ static void store_state(const orc_model *m, const orc_data *d, orc_state *s, int
   for (int k = 0; k < m->nv; k++) s->qfrc_actuator[(size_t)i * m->nv + k] = (real)d->qfrc_actuator[k];
 }
 
-static int obs_size(const orc_model *m, const orc_envspec *e) { return m->nq + 2 * m->nv + 3 * e->nee; }
+static int obs_size(const orc_model *m, const orc_envspec *e) {
+  return (e->flags & ENV_OBS_QPOS_QVEL) ? m->nq + m->nv : m->nq + 2 * m->nv + 3 * e->nee;
+}
 static int traj_size(const orc_envspec *e) { return e->ref_len * (3 * e->napp + 6 * e->nb + 3 + e->njc); }
 
 /* rodent.py:119-176 reset: explicit start_frame and (already scaled) noise replace the JAX PRNG */
-int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const int32_t *start_frame,
-                  const real *noise, orc_state *s) {
+/* follow: NULL, or the other side's solver traces [B][n_frames][ORC_TRACE_INTS] (the reset's forward pass is entry 0 of an
+ * env) whose decisions the oracle takes instead of its own; report: [B][ORC_FOLLOW_REPORT] */
+int orc_env_reset_follow(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const int32_t *start_frame,
+                         const real *noise, orc_state *s, const int32_t *follow, real *report) {
   int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e);
   real *obs = ralloc(no), *traj = ralloc(nt);
   orc_data *d = orc_data_create(m);
@@ -1439,7 +1452,10 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
     for (int k = 0; k < nj; k++) d->qvel[6 + k] = (real)c->joints_velocity[f * nj + k];
     memset(d->act, 0, sizeof(real) * m->nu), memset(d->ctrl, 0, sizeof(real) * m->nu);
     memset(d->qacc_warmstart, 0, sizeof(real) * m->nv);
+    d->follow = follow ? (const int *)follow + (size_t)i * (e->n_frames > 0 ? e->n_frames : 1) * ORC_TRACE_INTS : NULL;
     orc_forward(m, d); /* brax pipeline_init = mjx.forward */
+    d->follow = NULL;
+    if (report && follow) memcpy(report + (size_t)i * ORC_FOLLOW_REPORT, d->follow_report, sizeof(d->follow_report));
     if (g_opt.reset_warmstart_zero) memset(d->qacc_warmstart, 0, sizeof(real) * m->nv);
     store_state(m, d, s, i);
     env_traj(m, e, c, d, start_frame[i], traj);
@@ -1456,35 +1472,50 @@ int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, i
   return 0;
 }
 
-/* rodent.py:183-239: everything of `step` after pipeline_step.  `d` holds the NEW pipeline state (qpos, qvel, act,
- * qacc_warmstart and, from its last forward, xpos, xmat[1], subtree_com[1], qfrc_actuator); old_* the state before
- * the step.  Writes row i of the outputs and advances the frame counters. */
+int orc_env_reset(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const int32_t *start_frame,
+                  const real *noise, orc_state *s) {
+  return orc_env_reset_follow(m, e, c, B, start_frame, noise, s, NULL, NULL);
+}
+
+/* rodent.py:183-239 / humanoid.py:190-239: everything of `step` after pipeline_step.  `d` holds the NEW pipeline state
+ * (qpos, qvel, act, qacc_warmstart and, from its last forward, xpos, xmat[1], subtree_com[1], qfrc_actuator); old_* the
+ * state before the step.  Writes row i of the outputs and advances the frame counters. */
+typedef struct {
+  const real *qpos, *qvel, *com1, *qfrc_actuator, *xpos;
+} reward_state;
+
 static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, const orc_data *d, const real *old_qpos,
-                     const real *old_xpos, real *obs, real *traj, orc_state *s, int i) {
+                     const real *old_xpos, const reward_state *old /* state before the step, for ENV_REWARD_OLD_STATE */,
+                     real *obs, real *traj, orc_state *s, int i) {
   int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e);
   int old_frame = s->cur_frame[i], new_frame = old_frame + 1, new_sub = s->sub_clip_frame[i] + 1;
   env_obs(m, e, d, obs);
   env_traj(m, e, c, d, new_frame, traj);
-  /* _calculate_reward(state, data): NEW data vs clip row at OLD cur_frame (quirk C.1) */
+  /* _calculate_reward: rodent.py:195 passes the NEW data (quirk C.1: against the clip row at the OLD cur_frame);
+   * humanoid.py:195 passes `state`, i.e. every term comes from the state BEFORE the step */
+  reward_state cur = {d->qpos, d->qvel, d->subtree_com + 3, d->qfrc_actuator, d->xpos};
+  const reward_state *r = (e->flags & ENV_REWARD_OLD_STATE) ? old : &cur;
   int fo = clampi(old_frame, 0, e->T - 1);
   real dv[3], acc;
-  for (int k = 0; k < 3; k++)
-    dv[k] = d->subtree_com[3 + k] - (real)c->body_positions[(fo * e->nb + e->com_ref_col) * 3 + k];
+  for (int k = 0; k < 3; k++) {
+    real ref = c->center_of_mass ? (real)c->center_of_mass[fo * 3 + k] : (real)c->body_positions[(fo * e->nb + e->com_ref_col) * 3 + k];
+    dv[k] = r->com1[k] - ref;
+  }
   real rcom = REXP(-100 * norm3(dv));
   acc = 0;
   for (int k = 0; k < 3; k++) {
-    real a = d->qvel[k] - (real)c->velocity[fo * 3 + k], b = d->qvel[3 + k] - (real)c->angular_velocity[fo * 3 + k];
+    real a = r->qvel[k] - (real)c->velocity[fo * 3 + k], b = r->qvel[3 + k] - (real)c->angular_velocity[fo * 3 + k];
     acc += a * a + b * b;
   }
   for (int k = 0; k < nj; k++) {
-    real a = d->qvel[6 + k] - (real)c->joints_velocity[fo * nj + k];
+    real a = r->qvel[6 + k] - (real)c->joints_velocity[fo * nj + k];
     acc += a * a;
   }
   real rvel = REXP((real)-0.1 * RSQRT(acc));
   /* rtrunk from the OLD pipeline state and OLD frame (quirk C.2) */
   real rtrunk = env_termination(m, e, c, old_qpos, old_xpos, old_frame);
   real qc[4], qr[4], nc = 0, nr = 0, dq = 0;
-  for (int k = 0; k < 4; k++) qc[k] = d->qpos[3 + k], qr[k] = (real)c->quaternion[fo * 4 + k];
+  for (int k = 0; k < 4; k++) qc[k] = r->qpos[3 + k], qr[k] = (real)c->quaternion[fo * 4 + k];
   for (int k = 0; k < 4; k++) nc += qc[k] * qc[k], nr += qr[k] * qr[k];
   nc = RSQRT(nc), nr = RSQRT(nr);
   for (int k = 0; k < 4; k++) dq += (qc[k] / nc) * (qr[k] / nr);
@@ -1492,22 +1523,25 @@ static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c
   if (dist > 1) dist = 1;
   real rquat = REXP(-2 * RFABS((real)0.5 * RACOS(dist)));
   acc = 0;
-  for (int k = 0; k < m->nv; k++) acc += d->qfrc_actuator[k] * d->qfrc_actuator[k];
+  for (int k = 0; k < m->nv; k++) acc += r->qfrc_actuator[k] * r->qfrc_actuator[k];
   real ract = (real)-0.015 * (acc / m->nv);
-  acc = 0;
-  for (int a = 0; a < e->napp; a++)
-    for (int k = 0; k < 3; k++) {
-      real x = d->xpos[3 * e->app_body[a] + k] - (real)c->body_positions[(fo * e->nb + e->app_ref_col[a]) * 3 + k];
-      acc += x * x;
-    }
-  real rapp = REXP(-400 * RSQRT(acc));
+  real rapp = 0;
+  if (!(e->flags & ENV_NO_RAPP)) {
+    acc = 0;
+    for (int a = 0; a < e->napp; a++)
+      for (int k = 0; k < 3; k++) {
+        real x = r->xpos[3 * e->app_body[a] + k] - (real)c->body_positions[(fo * e->nb + e->app_ref_col[a]) * 3 + k];
+        acc += x * x;
+      }
+    rapp = REXP(-400 * RSQRT(acc));
+  }
   real healthy = 1;
-  if (d->qpos[2] < (real)e->healthy_z_lo) healthy = 0;
-  if (d->qpos[2] > (real)e->healthy_z_hi) healthy = 0;
+  if (r->qpos[2] < (real)e->healthy_z_lo) healthy = 0;
+  if (r->qpos[2] > (real)e->healthy_z_hi) healthy = 0;
+  real done = rtrunk < (real)e->done_threshold ? 1 : 0; /* on the unscaled value */
   rcom *= (real)0.01, rvel *= (real)0.01, rapp *= (real)0.01, rtrunk *= (real)0.01, rquat *= (real)0.01;
   ract *= (real)0.0001;
   real total = rcom + rvel + rtrunk + rquat + ract + rapp;
-  real done = rtrunk < 0 ? 1 : 0;
   if (1 - healthy > done) done = 1 - healthy;
   real sub_ok = new_sub < e->sub_clip_length ? 1 : 0;
   if (1 - sub_ok > done) done = 1 - sub_ok;
@@ -1534,12 +1568,16 @@ int orc_env_step_follow(const orc_model *m, const orc_envspec *e, const orc_clip
 #pragma omp parallel
   {
     real *obs = ralloc(no), *traj = ralloc(nt), *old_qpos = ralloc(m->nq), *old_xpos = ralloc(nb3);
+    real *old_qvel = ralloc(m->nv), *old_qfrc = ralloc(m->nv), old_com[3];
     orc_data *d = orc_data_create(m);
 #pragma omp for schedule(static)
     for (int i = 0; i < B; i++) {
       load_state(m, d, s, i);
       for (int k = 0; k < m->nq; k++) old_qpos[k] = d->qpos[k];
       for (int k = 0; k < nb3; k++) old_xpos[k] = (real)s->xpos[(size_t)i * nb3 + k];
+      for (int k = 0; k < m->nv; k++) old_qvel[k] = d->qvel[k], old_qfrc[k] = s->qfrc_actuator[(size_t)i * m->nv + k];
+      for (int k = 0; k < 3; k++) old_com[k] = s->com1[(size_t)i * 3 + k];
+      reward_state old = {old_qpos, old_qvel, old_com, old_qfrc, old_xpos};
       for (int k = 0; k < m->nu; k++) d->ctrl[k] = (real)action[(size_t)i * m->nu + k];
       for (int f = 0; f < e->n_frames; f++) { /* brax pipeline_step */
         d->follow = follow ? (const int *)follow + ((size_t)i * e->n_frames + f) * ORC_TRACE_INTS : NULL;
@@ -1550,10 +1588,10 @@ int orc_env_step_follow(const orc_model *m, const orc_envspec *e, const orc_clip
           memcpy(report + ((size_t)i * e->n_frames + f) * ORC_FOLLOW_REPORT, d->follow_report, sizeof(d->follow_report));
       }
       store_state(m, d, s, i);
-      env_glue(m, e, c, d, old_qpos, old_xpos, obs, traj, s, i);
+      env_glue(m, e, c, d, old_qpos, old_xpos, &old, obs, traj, s, i);
     }
     orc_data_destroy(d);
-    free(obs), free(traj), free(old_qpos), free(old_xpos);
+    free(obs), free(traj), free(old_qpos), free(old_xpos), free(old_qvel), free(old_qfrc);
   }
   return 0;
 }
@@ -1570,7 +1608,8 @@ int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
  * [B][nq], old_xpos [B][3 nbody] the state before the step.  Fills obs / traj / reward / done / metrics /
  * termination_error and advances the counters, exactly as orc_env_step does after its substeps. */
 int orc_env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *old_qpos,
-                 const real *old_xpos, orc_state *s) {
+                 const real *old_xpos, const real *old_qvel, const real *old_com1, const real *old_qfrc /* ENV_REWARD_OLD_STATE
+                 only: [B][nv], [B][3], [B][nv] before the step, else NULL */, orc_state *s) {
   int no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
   real *obs = ralloc(no), *traj = ralloc(nt);
   orc_data *d = orc_data_create(m);
@@ -1580,7 +1619,11 @@ int orc_env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
     for (int k = 0; k < 9; k++) d->xmat[9 + k] = s->xmat1[(size_t)i * 9 + k];
     for (int k = 0; k < 3; k++) d->subtree_com[3 + k] = s->com1[(size_t)i * 3 + k];
     for (int k = 0; k < m->nv; k++) d->qfrc_actuator[k] = s->qfrc_actuator[(size_t)i * m->nv + k];
-    env_glue(m, e, c, d, old_qpos + (size_t)i * m->nq, old_xpos + (size_t)i * nb3, obs, traj, s, i);
+    reward_state old = {old_qpos + (size_t)i * m->nq, old_qvel ? old_qvel + (size_t)i * m->nv : NULL,
+                        old_com1 ? old_com1 + (size_t)i * 3 : NULL, old_qfrc ? old_qfrc + (size_t)i * m->nv : NULL,
+                        old_xpos + (size_t)i * nb3};
+    if ((e->flags & ENV_REWARD_OLD_STATE) && !(old_qvel && old_com1 && old_qfrc)) return -1;
+    env_glue(m, e, c, d, old_qpos + (size_t)i * m->nq, old_xpos + (size_t)i * nb3, &old, obs, traj, s, i);
   }
   orc_data_destroy(d);
   free(obs), free(traj);

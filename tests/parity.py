@@ -226,7 +226,7 @@ def assert_legitimate(rep: np.ndarray) -> dict:
     return s
 
 
-def resync_substeps(env1, o64, o32, sf, noise, action, nsub=5):
+def resync_substeps(env1, o64, o32, sf, noise, action, nsub=5, assert_legit=True):
     """env1 / oracles: n_frames = 1.  Runs `nsub` consecutive substeps of the product; before each one the oracles are
     reloaded with the product's own state, so every comparison is ONE substep on identical inputs (nothing compounds).
     Returns one (err, dev32, report) per substep."""
@@ -240,7 +240,8 @@ def resync_substeps(env1, o64, o32, sf, noise, action, nsub=5):
         st[0] = new
         out.append((err, dev, rep))
         try:
-            assert_legitimate(rep)
+            if assert_legit:
+                assert_legitimate(rep)
         except AssertionError:
             save_last(os.path.join(H.ROOT, "gpurun_out", f"parity_fail_substep{len(out) - 1}_B{env1.num_envs}.npz"), report=rep)
             env1.debug(0)
@@ -298,24 +299,24 @@ GLUE_KEYS = ("obs", "traj", "reward", "done", "termination_error")
 METRIC_NAMES = ("rcom", "rvel", "rtrunk", "rquat", "ract", "rapp", "termination_error")
 
 
-def _glue_run(env, oracle, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=False):
+def _glue_run(env, oracle, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=False, old_extra=None):
     ost = oracle_state_from(env, oracle, state)
     if f32:
         ost = _as_f32_state(ost)
     ost["cur_frame"][:] = old_cur_frame
     ost["sub_clip_frame"][:] = old_sub_frame
-    oracle.env_glue(ost, old_qpos, old_xpos)
+    oracle.env_glue(ost, old_qpos, old_xpos, *(old_extra or ()))
     return ost
 
 
-def glue_errors(env, o64, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame):
+def glue_errors(env, o64, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, old_extra=None):
     """obs / traj / the reward terms / done / counters of the product's step against the oracle's glue evaluated on
     the product's OWN post-step pipeline state (so physics sensitivity cannot mask a glue error).  Returns (err, dev32,
     flags): per-env errors vs the float64 oracle scaled by each array's scale, the float32 oracle's own deviation from
     the float64 one (rquat goes through arccos near 1, whose float32 conditioning is part of the reference's own
     arithmetic), and the exact-equality flags."""
-    a = _glue_run(env, o64, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame)
-    b = _glue_run(env, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=True)
+    a = _glue_run(env, o64, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, old_extra=old_extra)
+    b = _glue_run(env, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=True, old_extra=old_extra)
     err = {"obs": per_env_scaled(to_np(state.obs), a["obs"]), "traj": per_env_scaled(to_np(state.info["traj"]), a["traj"])}
     dev = {"obs": per_env_scaled(b["obs"], a["obs"]), "traj": per_env_scaled(b["traj"], a["traj"])}
 

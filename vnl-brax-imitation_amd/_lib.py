@@ -42,7 +42,13 @@ class EnvSpec(C.Structure):
         ("velocity", f32p),
         ("angular_velocity", f32p),
         ("joints_velocity", f32p),
+        ("flags", C.c_int32),
+        ("done_threshold", C.c_float),
+        ("center_of_mass", f32p),
     ]
+
+
+ENV_REWARD_OLD_STATE, ENV_TERM_MEAN, ENV_NO_RAPP, ENV_OBS_QPOS_QVEL = 1, 2, 4, 8  # include/vnl.h VNL_ENV_*
 
 
 STATE_FLOAT_FIELDS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xquat", "subtree_com1", "qfrc_actuator",

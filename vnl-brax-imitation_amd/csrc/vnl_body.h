@@ -2035,6 +2035,10 @@ struct EnvWave {
     }
     ej = vnl_wave_sum(ej), cx = vnl_wave_sum(cx), cy = vnl_wave_sum(cy), cz = vnl_wave_sum(cz);
     vreal eb = fmax(cx, fmax(cy, cz));
+    if (ev.flags & VNL_ENV_TERM_MEAN) {  // humanoid.py:256-260: jp.mean(jp.abs(.)) over the (nb, 3) and (nj,) differences
+      eb = (cx + cy + cz) / vreal(3 * ev.nb);
+      ej = ej / vreal(nj);
+    }
     vreal err = vreal(0.5) * ev.body_err_mult * eb + vreal(0.5) * ej;
     return vreal(1.) - err * ev.inv_term_threshold;
   }
@@ -2088,6 +2092,7 @@ struct EnvWave {
     vreal* o = st.obs + (size_t)e * ev.obs_size;
     VNL_FOR(i, m.nq) o[i] = nan0(s[L.qpos + i]);
     VNL_FOR(i, m.nv) o[m.nq + i] = nan0(s[L.qvel + i]);
+    if (ev.flags & VNL_ENV_OBS_QPOS_QVEL) return;  // humanoid.py:354-368
     const vreal* gf = gqfrc_act();
     const vreal* gx = gxpos();
     VNL_FOR(i, m.nv) o[m.nq + m.nv + i] = nan0(gf[i]);
@@ -2163,7 +2168,54 @@ struct EnvWave {
     }
   }
 
-  // RodentTracking.step, rodent.py:178-239
+  // _calculate_reward (rodent.py:266-316 / humanoid.py:264-311) on a pipeline state given by pointers, against the clip
+  // row at `frame`; unscaled terms
+  struct RewardTerms {
+    vreal rcom, rvel, rquat, ract, rapp, healthy;
+  };
+  VNL_HD RewardTerms reward_terms(int clip, int frame, const vreal* qpos, const vreal* qvel, const vreal* com, const vreal* qfrc,
+                                  const vreal* xpos) const {
+    int fo = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
+    size_t fb = (size_t)clip * ev.T + fo;
+    const float* cb = ev.body_positions + fb * ev.nb * 3;
+    const float* cref = ev.center_of_mass ? ev.center_of_mass + fb * 3 : cb + 3 * ev.com_ref_col;
+    V3 dc = V3{com[0] - vreal(cref[0]), com[1] - vreal(cref[1]), com[2] - vreal(cref[2])};
+    RewardTerms r;
+    r.rcom = exp(vreal(-100.) * sqrt(dot(dc, dc)));
+    vreal acc = vreal(0.);
+    VNL_FOR(k, m.nv) {
+      vreal ref = k < 3 ? ev.velocity[fb * 3 + k] : (k < 6 ? ev.angular_velocity[fb * 3 + k - 3] : ev.joints_velocity[fb * nj + k - 6]);
+      vreal a = qvel[k] - ref;
+      acc += a * a;
+    }
+    r.rvel = exp(vreal(-0.1) * sqrt(vnl_wave_sum(acc)));
+    vreal nc = vreal(0.), nr = vreal(0.), dq = vreal(0.);
+    for (int k = 0; k < 4; k++) {
+      vreal a = qpos[3 + k], b = ev.quaternion[fb * 4 + k];
+      nc += a * a, nr += b * b, dq += a * b;
+    }
+    dq = dq / (sqrt(nc) * sqrt(nr));
+    vreal dist = fmin(vreal(1.), vreal(2.) * dq * dq - vreal(1.));
+    r.rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
+    acc = vreal(0.);
+    VNL_FOR(d, m.nv) acc += qfrc[d] * qfrc[d];
+    r.ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
+    r.rapp = vreal(0.);
+    if (!(ev.flags & VNL_ENV_NO_RAPP)) {
+      acc = vreal(0.);
+      VNL_FOR(k, 3 * ev.napp) {
+        int a = k / 3, i = k % 3;
+        vreal x = xpos[3 * ev.app_body[a] + i] - vreal(cb[3 * ev.app_ref_col[a] + i]);
+        acc += x * x;
+      }
+      r.rapp = exp(vreal(-400.) * sqrt(vnl_wave_sum(acc)));
+    }
+    vreal z = qpos[2];
+    r.healthy = (z < ev.healthy_lo || z > ev.healthy_hi) ? vreal(0.) : vreal(1.);
+    return r;
+  }
+
+  // RodentTracking.step, rodent.py:178-239 (HumanoidTracking.step, humanoid.py:185-239, by the env flags)
   // dump_mid / trace_base: debug only (vnl_env_debug), null in normal use
   VNL_HD void step(const vreal* action, vreal* dump_mid, int* trace_base) const {
     prof_begin();
@@ -2180,6 +2232,16 @@ struct EnvWave {
     }
     VNL_SYNC();
     const vreal* gw = st.warm + (size_t)e * m.nv;
+    if (ev.flags & VNL_ENV_REWARD_OLD_STATE) {  // humanoid.py:195,264-311: every term from the state BEFORE the step
+      // (parked in this env's metrics row across the substeps: six values kept in registers over the whole physics would
+      // raise the kernel's register allocation past two waves per SIMD)
+      const RewardTerms r0 = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, st.com1 + (size_t)e * 3, gqfrc_act(), gxpos());
+      VNL_SERIAL {
+        vreal* mt = st.metrics + (size_t)e * 7;
+        mt[0] = r0.rcom, mt[1] = r0.rvel, mt[2] = r0.rquat, mt[3] = r0.ract, mt[4] = r0.rapp, mt[5] = r0.healthy;
+      }
+      VNL_SYNC();
+    }
     VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
       fresh().with_trace(trace_of(trace_base, f)).forward(f == 0 ? gw : s + L.qacc);
@@ -2187,44 +2249,20 @@ struct EnvWave {
       fresh().euler();
     }
     int new_frame = old_frame + 1, new_sub = old_sub + 1;
-    int fo = clampi(old_frame, 0, ev.T - 1), nj = m.nq - 7;
-    size_t fb = (size_t)clip * ev.T + fo;
-    // _calculate_reward: NEW data vs clip row at OLD frame (rodent.py:266-316)
-    const float* cb = ev.body_positions + fb * ev.nb * 3;
-    V3 dc = V3{s[L.com] - vreal(cb[3 * ev.com_ref_col]), s[L.com + 1] - vreal(cb[3 * ev.com_ref_col + 1]),
-               s[L.com + 2] - vreal(cb[3 * ev.com_ref_col + 2])};
-    vreal rcom = exp(vreal(-100.) * sqrt(dot(dc, dc)));
-    vreal acc = vreal(0.);
-    VNL_FOR(k, m.nv) {
-      vreal ref = k < 3 ? ev.velocity[fb * 3 + k] : (k < 6 ? ev.angular_velocity[fb * 3 + k - 3] : ev.joints_velocity[fb * nj + k - 6]);
-      vreal a = s[L.qvel + k] - ref;
-      acc += a * a;
+    RewardTerms rw;
+    if (!(ev.flags & VNL_ENV_REWARD_OLD_STATE)) {  // rodent.py:195: _calculate_reward(state, data) -- the NEW data
+      rw = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, s + L.com, gqfrc_act(), gxpos());
+    } else {
+      const vreal* mt = st.metrics + (size_t)e * 7;
+      rw = RewardTerms{mt[0], mt[1], mt[2], mt[3], mt[4], mt[5]};
+      VNL_SYNC();  // (every lane has read the parked values before lane 0 rewrites the row below)
     }
-    vreal rvel = exp(vreal(-0.1) * sqrt(vnl_wave_sum(acc)));
-    vreal nc = vreal(0.), nr = vreal(0.), dq = vreal(0.);
-    for (int k = 0; k < 4; k++) {
-      vreal a = s[L.qpos + 3 + k], b = ev.quaternion[fb * 4 + k];
-      nc += a * a, nr += b * b, dq += a * b;
-    }
-    dq = dq / (sqrt(nc) * sqrt(nr));
-    vreal dist = fmin(vreal(1.), vreal(2.) * dq * dq - vreal(1.));
-    vreal rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
-    acc = vreal(0.);
-    VNL_FOR(d, m.nv) acc += gqfrc_act()[d] * gqfrc_act()[d];
-    vreal ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
-    acc = vreal(0.);
-    VNL_FOR(k, 3 * ev.napp) {
-      int a = k / 3, i = k % 3;
-      vreal x = gxpos()[3 * ev.app_body[a] + i] - vreal(cb[3 * ev.app_ref_col[a] + i]);
-      acc += x * x;
-    }
-    vreal rapp = exp(vreal(-400.) * sqrt(vnl_wave_sum(acc)));
-    vreal z = s[L.qpos + 2];
-    vreal healthy = (z < ev.healthy_lo || z > ev.healthy_hi) ? vreal(0.) : vreal(1.);
-    rcom *= vreal(0.01), rvel *= vreal(0.01), rapp *= vreal(0.01), rtrunk *= vreal(0.01), rquat *= vreal(0.01), ract *= vreal(0.0001);
+    vreal rcom = rw.rcom * vreal(0.01), rvel = rw.rvel * vreal(0.01), rapp = rw.rapp * vreal(0.01), rquat = rw.rquat * vreal(0.01);
+    vreal ract = rw.ract * vreal(0.0001);
+    const vreal done_trunk = rtrunk < ev.done_threshold ? vreal(1.) : vreal(0.);  // on the unscaled value (rodent.py:213: < 0)
+    rtrunk *= vreal(0.01);
     vreal total = rcom + rvel + rtrunk + rquat + ract + rapp;
-    vreal done = rtrunk < vreal(0.) ? vreal(1.) : vreal(0.);
-    done = fmax(vreal(1.) - healthy, done);
+    vreal done = fmax(vreal(1.) - rw.healthy, done_trunk);
     done = fmax(new_sub < ev.sub_clip_length ? vreal(0.) : vreal(1.), done);
     if (store_state()) done = vreal(1.);
     write_obs();

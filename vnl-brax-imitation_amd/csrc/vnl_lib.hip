@@ -550,7 +550,8 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   e.njc = es->num_joint_cols, e.com_ref_col = es->com_ref_col;
   e.healthy_lo = es->healthy_z_lo, e.healthy_hi = es->healthy_z_hi;
   e.inv_term_threshold = vreal(1) / es->termination_threshold, e.body_err_mult = es->body_error_multiplier;
-  e.obs_size = d.nq + 2 * d.nv + 3 * e.nee;
+  e.flags = es->flags, e.done_threshold = es->done_threshold, e.center_of_mass = nullptr;
+  e.obs_size = (e.flags & VNL_ENV_OBS_QPOS_QVEL) ? d.nq + d.nv : d.nq + 2 * d.nv + 3 * e.nee;
   e.traj_size = e.ref_len * (3 * e.napp + 6 * e.nb + 3 + e.njc);
   bool ok = e.T >= e.ref_len && e.C >= 1 && e.nb >= 1 && e.com_ref_col >= 0 && e.com_ref_col < e.nb && d.nq >= 7 &&
             d.root_free;
@@ -581,6 +582,7 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   UP(upload_raw<float>(env, es->velocity, CT * 3, &e.velocity))
   UP(upload_raw<float>(env, es->angular_velocity, CT * 3, &e.angular_velocity))
   UP(upload_raw<float>(env, es->joints_velocity, CT * nj, &e.joints_velocity))
+  if (es->center_of_mass) UP(upload_raw<float>(env, es->center_of_mass, CT * 3, &e.center_of_mass))
 #undef UP
   {
     void* p = nullptr;

@@ -75,9 +75,11 @@ struct DevModel {
 struct DevEnv {
   int T, C, ref_len, sub_clip_length, n_frames, nb, nee, napp, njc, com_ref_col;
   int obs_size, traj_size;
-  vreal healthy_lo, healthy_hi, inv_term_threshold, body_err_mult;
+  int flags; /* VNL_ENV_* of include/vnl.h: which tracking env's glue (rodent / humanoid style) */
+  vreal healthy_lo, healthy_hi, inv_term_threshold, body_err_mult, done_threshold;
   const int *body_idxs, *end_eff_idx, *app_body, *app_ref_col, *joint_cols;
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
+  const float* center_of_mass; /* (C,T,3) or null: reference for rcom (else body_positions[com_ref_col]) */
   vreal* fac2; /* library-owned scratch [num_envs][nM + nv]: the second factor of a substep (EnvWave::factor_pair) */
 };
 

@@ -6,6 +6,7 @@ from __future__ import annotations
 from typing import Callable, Dict
 
 from .base import Env, PipelineState, State  # noqa: F401
+from .humanoid import HumanoidTracking  # noqa: F401
 from .rodent import RodentMultiClipTracking, RodentTracking  # noqa: F401
 
 _envs: Dict[str, Callable[..., Env]] = {}
@@ -21,3 +22,4 @@ def get_environment(env_name: str, **kwargs) -> Env:
 
 register_environment("rodent", RodentTracking)
 register_environment("rodent_multiclip", RodentMultiClipTracking)
+register_environment("humanoidtracking", HumanoidTracking)  # reference train.py:66

@@ -30,7 +30,9 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _METRICS = ("rcom", "rvel", "rtrunk", "rquat", "ract", "rapp", "termination_error")
 
 
-def packaged_model_path(name: str = "rodent", scale_factor: float = 0.9) -> str:
+def packaged_model_path(name: str = "rodent", scale_factor: Optional[float] = 0.9) -> str:
+    if scale_factor is None:  # models compiled without the dm_control rescale (humanoid, ant)
+        return os.path.join(_PKG, "data", f"{name}.npz")
     return os.path.join(_PKG, "data", f"{name}_scale{scale_factor:g}.npz")
 
 
@@ -105,6 +107,16 @@ class RodentTracking(Env):
         if self._sub_clip_length > self._clip_length:
             raise ValueError("episode_length cannot be greater than clip_length!")  # rodent.py:116-117
 
+        self._build(reference_clip, num_envs, device, _library, _dtype)
+
+    # env-variant knobs (include/vnl.h VNL_ENV_*): RodentTracking's glue by default
+    _env_flags = 0
+    _done_threshold = 0.0
+    _use_clip_com = False
+
+    def _build(self, reference_clip, num_envs, device, _library, _dtype):
+        m = self.sys
+        healthy_z_range = self._healthy_z_range
         # --- clip (rodent.py:112-115): filter body_positions to the tracked bodies -----
         clip = reference_clip.as_multi() if hasattr(reference_clip, "as_multi") else reference_clip
         f32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)  # noqa: E731
@@ -115,6 +127,8 @@ class RodentTracking(Env):
             velocity=f32(clip.velocity), angular_velocity=f32(clip.angular_velocity),
             joints_velocity=f32(clip.joints_velocity),
         )
+        if self._use_clip_com:
+            self._clip["center_of_mass"] = f32(clip.center_of_mass)
         self._num_clips, self._T = self._clip["position"].shape[:2]
         nb = len(self._body_idxs)
         nj = int(m.scalars["nq"]) - 7
@@ -150,6 +164,7 @@ class RodentTracking(Env):
         spec.app_ref_col, spec.joint_cols = ip(self._app_ref_col), ip(self._joint_cols)
         spec.healthy_z_lo, spec.healthy_z_hi = float(healthy_z_range[0]), float(healthy_z_range[1])
         spec.termination_threshold, spec.body_error_multiplier = self._termination_threshold, self._body_error_multiplier
+        spec.flags, spec.done_threshold = int(self._env_flags), float(self._done_threshold)
         for k, v in self._clip.items():
             setattr(spec, k, fp(v))
         self._env_h = C.c_void_p()
@@ -196,7 +211,8 @@ class RodentTracking(Env):
             app_body=self._app_idx.tolist(), app_ref_col=self._app_ref_col.tolist(),
             joint_cols=self._joint_cols.tolist(), healthy_z_lo=self._healthy_z_range[0],
             healthy_z_hi=self._healthy_z_range[1], termination_threshold=self._termination_threshold,
-            body_error_multiplier=self._body_error_multiplier,
+            body_error_multiplier=self._body_error_multiplier, flags=int(self._env_flags),
+            done_threshold=float(self._done_threshold),
         )
 
     def clip_arrays(self, clip: int = 0) -> Dict[str, np.ndarray]:

@@ -143,9 +143,11 @@ class _Defaults:
             if child.tag == "default":
                 self._walk(child, child.attrib["class"], cur)
 
-    def resolve(self, elem: ET.Element, tag: Optional[str] = None) -> Dict[str, str]:
+    def resolve(self, elem: ET.Element, tag: Optional[str] = None, childclass: Optional[str] = None) -> Dict[str, str]:
+        """Attributes of `elem` after default-class resolution: its own `class`, else the `childclass` of the nearest
+        enclosing body that sets one, else the top-level defaults."""
         tag = tag or elem.tag
-        cls = elem.attrib.get("class", "main")
+        cls = elem.attrib.get("class", childclass or "main")
         out = dict(self.classes.get(cls, {}).get(tag, {}))
         out.update(elem.attrib)
         return out
@@ -309,8 +311,17 @@ def compile_mjcf(
             v = v * sf
         return v
 
-    def add_geom(elem: ET.Element, body: int):
-        a = defaults.resolve(elem)
+    def zaxis_quat(z: np.ndarray) -> np.ndarray:
+        """quaternion rotating (0,0,1) onto z  [MuJoCo mjuu_z2quat]"""
+        z = z / np.linalg.norm(z)
+        axis = np.cross([0, 0, 1.0], z)
+        s = np.linalg.norm(axis)
+        if s < 1e-10:
+            return np.array([1.0, 0, 0, 0]) if z[2] > 0 else np.array([0.0, 1.0, 0, 0])
+        return axis_angle_quat(axis / s, np.arctan2(s, z[2]))
+
+    def add_geom(elem: ET.Element, body: int, childclass: Optional[str] = None):
+        a = defaults.resolve(elem, childclass=childclass)
         gtype = _GEOM_TYPES[a.get("type", "sphere")]
         size = scaled(elem, a, "size")
         size = np.zeros(3) if size is None else np.concatenate([size, np.zeros(3)])[:3]
@@ -334,7 +345,7 @@ def compile_mjcf(
         else:
             pos = scaled(elem, a, "pos")
             pos = np.zeros(3) if pos is None else pos
-            quat = orient(a)
+            quat = zaxis_quat(_floats(a["zaxis"])) if "zaxis" in a else orient(a)
         fr = np.array([1.0, 0.005, 0.0001])
         f = _floats(a.get("friction"))
         if f is not None:
@@ -368,11 +379,11 @@ def compile_mjcf(
             g.mass = g.density * _geom_volume(gtype, size)
         geoms.append(g)
 
-    def add_joint(elem: ET.Element, body: int):
+    def add_joint(elem: ET.Element, body: int, childclass: Optional[str] = None):
         if elem.tag == "freejoint":
             joints.append(dict(name=elem.attrib.get("name", ""), type=JNT_FREE, body=body))
             return
-        a = defaults.resolve(elem, "joint")
+        a = defaults.resolve(elem, "joint", childclass=childclass)
         jtype = a.get("type", "hinge")
         if jtype == "free":
             joints.append(dict(name=a.get("name", ""), type=JNT_FREE, body=body))
@@ -405,14 +416,14 @@ def compile_mjcf(
             )
         )
 
-    def walk(elem: ET.Element, body: int):
+    def walk(elem: ET.Element, body: int, childclass: Optional[str] = None):
         # MuJoCo numbering: a body's joints and geoms are registered when the body is
         # visited (document order within the body), then children depth-first.
         for child in elem:
             if child.tag in ("joint", "freejoint"):
-                add_joint(child, body)
+                add_joint(child, body, childclass)
             elif child.tag == "geom":
-                add_geom(child, body)
+                add_geom(child, body, childclass)
         for child in elem:
             if child.tag == "body":
                 bid = len(body_names)
@@ -421,7 +432,7 @@ def compile_mjcf(
                 p = _floats(child.attrib.get("pos"))
                 body_pos.append(np.zeros(3) if p is None else p * sf)
                 body_quat.append(orient(child.attrib))
-                walk(child, bid)
+                walk(child, bid, child.attrib.get("childclass", childclass))  # `childclass`: defaults of the subtree
 
     walk(root.find("worldbody"), 0)
 
@@ -634,7 +645,7 @@ def compile_mjcf(
         timestep=timestep,
         tolerance=1e-8,
         ls_tolerance=0.01,
-        impratio=1.0,
+        impratio=float(opt.attrib.get("impratio", 1.0)) if opt is not None else 1.0,
         iterations=iterations,
         ls_iterations=ls_iterations,
         solver_newton=1 if solver.lower() == "newton" else 0,
@@ -648,12 +659,23 @@ def compile_mjcf(
     )
     model = CompiledModel(names=names, arrays=arrays, scalars=scalars)
 
-    _contact_tables(model, geoms)
+    # explicit <contact><pair>: collide whatever contype / conaffinity say (e.g. assets/humanoid.xml:189-197)
+    pairs = []
+    contact = root.find("contact")
+    if contact is not None:
+        gname = {g.name: i for i, g in enumerate(geoms)}
+        for pe in contact.findall("pair"):
+            pa = defaults.resolve(pe, "pair")
+            unsupported = [k for k in ("condim", "friction", "solref", "solimp", "margin", "gap") if k in pa]
+            if unsupported:
+                raise NotImplementedError(f"<pair> attributes {unsupported}: only geom-derived pair parameters are implemented")
+            pairs.append((gname[pa["geom1"]], gname[pa["geom2"]]))
+    _contact_tables(model, geoms, pairs)
     _set_const(model)
     return model
 
 
-def _contact_tables(model: CompiledModel, geoms: Sequence[_Geom]) -> None:
+def _contact_tables(model: CompiledModel, geoms: Sequence[_Geom], explicit_pairs: Sequence[tuple] = ()) -> None:
     """Static geom-vs-plane contact list.
 
     MJX [UPSTREAM collision_driver] emits a fixed set of contacts per candidate
@@ -666,17 +688,22 @@ def _contact_tables(model: CompiledModel, geoms: Sequence[_Geom]) -> None:
     """
     planes = [i for i, g in enumerate(geoms) if g.gtype == GEOM_PLANE]
     rows = []
+    explicit = {(min(a, b), max(a, b)) for a, b in explicit_pairs}
     for i, g1 in enumerate(geoms):
         for j in range(i + 1, len(geoms)):
             g2 = geoms[j]
-            if not ((g1.contype & g2.conaffinity) or (g2.contype & g1.conaffinity)):
-                continue
-            if g1.body == g2.body:
-                continue
-            # parent-child filter (MuJoCo filterparent; world-body parents are exempt)
-            bp = model.arrays["body_parentid"]
-            if g1.body != 0 and g2.body != 0 and (bp[g1.body] == g2.body or bp[g2.body] == g1.body):
-                continue
+            is_explicit = (i, j) in explicit
+            # explicit <pair>s bypass the filters; their unspecified parameters come from the two geoms by the
+            # equal-priority mixing rules below [MuJoCo user_objects mjCPair::Compile]
+            if not is_explicit:
+                if not ((g1.contype & g2.conaffinity) or (g2.contype & g1.conaffinity)):
+                    continue
+                if g1.body == g2.body:
+                    continue
+                # parent-child filter (MuJoCo filterparent; world-body parents are exempt)
+                bp = model.arrays["body_parentid"]
+                if g1.body != 0 and g2.body != 0 and (bp[g1.body] == g2.body or bp[g2.body] == g1.body):
+                    continue
             if i in planes:
                 p, o = g1, g2
                 pi_, oi = i, j
@@ -687,9 +714,9 @@ def _contact_tables(model: CompiledModel, geoms: Sequence[_Geom]) -> None:
                 raise NotImplementedError(f"non-plane collision pair {g1.name} / {g2.name}")
             if o.gtype not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID):
                 raise NotImplementedError(f"plane vs geom type {o.gtype}")
-            if p.priority > o.priority:
+            if p.priority > o.priority and not is_explicit:
                 fr, sr, si, cd = p.friction, p.solref, p.solimp, p.condim
-            elif o.priority > p.priority:
+            elif o.priority > p.priority and not is_explicit:
                 fr, sr, si, cd = o.friction, o.solref, o.solimp, o.condim
             else:
                 fr = np.maximum(p.friction, o.friction)

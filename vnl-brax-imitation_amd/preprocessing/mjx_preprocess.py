@@ -33,6 +33,7 @@ class ReferenceClip:
     joints_velocity: Optional[np.ndarray] = None
     angular_velocity: Optional[np.ndarray] = None
     body_quaternions: Optional[np.ndarray] = None
+    center_of_mass: Optional[np.ndarray] = None  # subtree_com of the root body (mocap_preprocess.py:334; envs/humanoid.py:273)
 
     def replace(self, **kw) -> "ReferenceClip":
         return dataclasses.replace(self, **kw)
@@ -50,7 +51,8 @@ class ReferenceClip:
 
     @staticmethod
     def stack(clips: Sequence["ReferenceClip"]) -> "ReferenceClip":
-        return ReferenceClip(**{f.name: np.stack([getattr(c, f.name) for c in clips])
+        return ReferenceClip(**{f.name: (None if getattr(clips[0], f.name) is None else
+                                         np.stack([getattr(c, f.name) for c in clips]))
                                 for f in dataclasses.fields(ReferenceClip)})
 
     def save(self, path: str) -> None:
@@ -132,9 +134,15 @@ def process_qpos(model: mjcf.CompiledModel, mocap_qpos: np.ndarray, max_qvel: fl
     padded = np.concatenate([mocap_qpos, mocap_qpos[-1:]], axis=0)
     qvel = compute_velocity_from_kinematics(padded, dt)
     qvel[:, 6:] = np.clip(qvel[:, 6:], -max_qvel, max_qvel)
+    # subtree centre of mass of the root body (body 1): mass-weighted mean of the bodies' inertial-frame origins
+    a = model.arrays
+    mass = np.asarray(a["body_mass"], dtype=np.float64)
+    xipos = xpos.astype(np.float64) + _qrot(np.broadcast_to(a["body_ipos"], xpos.shape), xquat.astype(np.float64))
+    sub = np.asarray(a["body_rootid"]) == 1
+    com = (mass[sub, None] * xipos[:, sub]).sum(1) / mass[sub].sum()
     return ReferenceClip(
         position=qn[:, :3], quaternion=qn[:, 3:7], joints=qn[:, 7:], body_positions=xpos, body_quaternions=xquat,
-        velocity=qvel[:, :3], angular_velocity=qvel[:, 3:6], joints_velocity=qvel[:, 6:],
+        velocity=qvel[:, :3], angular_velocity=qvel[:, 3:6], joints_velocity=qvel[:, 6:], center_of_mass=com.astype(np.float32),
     )
 
 
