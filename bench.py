@@ -87,10 +87,11 @@ def cpu_baseline(env, num_envs: int, max_steps: int = 200, budget_s: float = 12.
 
     o = H.make_oracle(env, "f32")
     rng = np.random.default_rng(seed)
-    sf = rng.integers(0, 235, num_envs).astype(np.int32)
-    noise = (1e-3 * rng.standard_normal((num_envs, 74))).astype(np.float32)
+    nq, nu = int(env.dims.nq), int(env.dims.nu)
+    sf = rng.integers(0, max(env._T - 15, 1), num_envs).astype(np.int32)
+    noise = (float(env._reset_noise_scale) * rng.standard_normal((num_envs, nq))).astype(np.float32)
     st = o.env_reset(sf, noise)
-    acts = np.clip(0.3 * rng.standard_normal((max_steps, num_envs, 30)), -1, 1).astype(np.float32)
+    acts = np.clip(0.3 * rng.standard_normal((max_steps, num_envs, nu)), -1, 1).astype(np.float32)
     o.env_step(st, acts[0])  # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     steps = 0
@@ -250,9 +251,10 @@ def main() -> None:
                 traffic, traffic_src = float(tf["bytes_per_launch"]), tf.get("source")
         workload = ("humanoid imitation rollout (HumanoidTracking, synthetic standing clip), " if args.config == "humanoid" else
                     "rodent imitation rollout, ") + (
-                    ("single groom clip, " if args.clips == 1 else f"{args.clips} synthesised clips (random clip per env), ") +
+                    ("" if args.config == "humanoid" else "single groom clip, " if args.clips == 1 else
+                     f"{args.clips} synthesised clips (random clip per env), ") +
                     f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else "intention-policy forward (HIP) -> ") +
-                    "RodentTracking.step (5 substeps, CG 6/6) -> " + f"auto-reset {'off' if args.no_autoreset else 'on'}" +
+                    f"{type(base).__name__}.step (5 substeps, CG 6/6) -> " + f"auto-reset {'off' if args.no_autoreset else 'on'}" +
                     ("" if args.random_actions else " -> Transition logging (unroll 20)"))
         out = {
             "metric": ("env-steps/sec (whole node), rodent imitation, num_envs=4096/GPU" if args.config == "rodent" else
