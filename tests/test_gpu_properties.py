@@ -91,3 +91,44 @@ def test_end_of_clip_matches_oracle():
     assert np.array_equal(st.done.cpu().numpy(), ost["done"].astype(np.float32))
     assert H.scaled_err(st.info["traj"].cpu().numpy(), ost["traj"]) < 1e-3
     assert torch.isfinite(st.obs).all()
+
+
+def test_multi_clip_at_full_size_64_clips_4096_envs():
+    """SURVEY 8(d) config 4, per-GPU share: 64 synthesised clips (yaw / shift / time reversal of the groom clip, seeded,
+    through process_qpos), 4096 envs with a random clip each.  At full size: every env must behave exactly like a single-clip
+    env of its own clip (bit for bit -- the clip index only selects rows); on a 64-env subsample: reset + control step against
+    the oracle bound to that env's clip."""
+    import parity as P
+    from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
+
+    C, B = 64, 4096
+    multi = pp.synthesize_clips(H.model(), H.golden_qpos(), C, seed=0)
+    rng = np.random.default_rng(11)
+    cid = rng.integers(0, C, B).astype(np.int32)
+    sf = rng.integers(0, 235, B).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
+    act = np.clip(0.3 * rng.standard_normal((B, 30)), -1, 1).astype(np.float32)
+    env = _make(B, reference_clip=multi)
+    st = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise), clip_id=torch.from_numpy(cid))
+    st = env.step(st, torch.from_numpy(act))
+    assert torch.isfinite(st.obs).all() and torch.isfinite(st.info["traj"]).all()
+    assert torch.equal(st.info["clip_id"].cpu(), torch.from_numpy(cid))
+    # three clips, every env that tracks them: identical to a single-clip env
+    for c in (0, int(cid[1]), C - 1):
+        idx = np.where(cid == c)[0]
+        if len(idx) == 0:
+            continue
+        single = pp.ReferenceClip(**{f: (None if getattr(multi, f) is None else getattr(multi, f)[c]) for f in
+                                     ("position", "quaternion", "joints", "body_positions", "velocity", "joints_velocity",
+                                      "angular_velocity", "body_quaternions", "center_of_mass")})
+        e1 = _make(len(idx), reference_clip=single)
+        s1 = e1.reset(start_frame=torch.from_numpy(sf[idx]), noise=torch.from_numpy(noise[idx]))
+        s1 = e1.step(s1, torch.from_numpy(act[idx]))
+        ti = torch.from_numpy(idx).to(st.obs.device)
+        for name, a, b in (("qpos", st.pipeline_state.qpos, s1.pipeline_state.qpos), ("obs", st.obs, s1.obs),
+                           ("traj", st.info["traj"], s1.info["traj"]), ("reward", st.reward, s1.reward)):
+            assert torch.equal(a[ti], b), (c, name)
+        if c == int(cid[1]):  # against the oracle bound to this clip, following the product's decisions
+            o64, o32 = H.make_oracle(e1, "f64"), H.make_oracle(e1, "f32")
+            _, err, dev, rep, _ = P.control_step_follow(e1, o64, o32, sf[idx], noise[idx], act[idx])
+            P.check_control_step(err, dev, rep, verbose=False)
