@@ -10,6 +10,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pb_rd -
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pb_rd vnl_ > $OUT/pmc_traffic.txt
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pb_wr -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_wr.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pb_wr vnl_ >> $OUT/pmc_traffic.txt
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pb_rd /tmp/pb_wr 4096 "${PROFILE_LABEL:-profiles/r02_pmc_traffic.txt}"
 tail -1 $OUT/bench_stats.log | cut -c1-300
 head -8 $OUT/kernel_stats.csv | cut -c1-160
 cat $OUT/pmc_traffic.txt
