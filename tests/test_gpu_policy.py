@@ -32,9 +32,10 @@ def test_hip_policy_matches_torch_and_numpy(B):
     P = {k: v.double().numpy() for k, v in n.policy_network.layout.views(flat).items()}
     obs_n = (obs.double().numpy() - st.mean.double().numpy()) / st.std.double().numpy()
     rl, rm, rv = O.policy_forward(P, ENC, list(DEC) + [60], traj.double().numpy(), obs_n, eps_l.double().numpy())
-    assert np.abs(ex["logits"].cpu().numpy() - rl).max() < 2e-4
-    assert np.abs(ex["latent_mean"].cpu().numpy() - rm).max() < 2e-4
-    assert np.abs(ex["latent_logvar"].cpu().numpy() - rv).max() < 2e-4
+    # float32 accumulation over K <= 1027 against the float64 restatement: 2e-5 absolute on O(1) outputs
+    errs = {k: np.abs(ex[k].cpu().numpy() - r).max() for k, r in (("logits", rl), ("latent_mean", rm), ("latent_logvar", rv))}
+    print("policy forward max abs error vs float64:", errs)
+    assert max(errs.values()) < 2e-5, errs
     dist = n.parametric_action_distribution
     lg = ex["logits"].cpu()
     raw = dist.sample_no_postprocessing(lg, eps_a)

@@ -20,7 +20,10 @@ st = running_statistics.init_state(232, device=dev)
 mk = ppo_networks.make_inference_fn(n)
 traj, obs = torch.randn((B, 795), device=dev) * 0.1, torch.randn((B, 232), device=dev)
 g = torch.Generator(device=dev).manual_seed(0)
+only = sys.argv[2] if len(sys.argv) > 2 else None  # "hip" / "torch": time one backend only (rocprofv3 runs)
 for name, pol in (("hip", mk((st, flat))), ("torch", mk((st, flat), backend="torch"))):
+    if only and name != only:
+        continue
     for _ in range(5):
         pol(traj, obs, g)
     torch.cuda.synchronize()

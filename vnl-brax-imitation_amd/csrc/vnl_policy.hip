@@ -4,14 +4,18 @@
 // and intention_policy_network.py:20-105 (Encoder -> reparameterize -> Decoder), plus the tanh-Normal
 // sampling / log-prob of brax NormalTanhDistribution [UPSTREAM].
 //
-// One 256-thread workgroup owns a tile of 32 envs for the whole network:
-//   traj tile (32 x 795) -> LDS -> [Dense+ReLU+LayerNorm] x len(encoder) -> fc2_mean / fc2_logvar
-//   -> z = mean + eps * exp(logvar / 2) -> [z | (obs - mu) / sigma] -> decoder -> logits (32 x 60)
+// One 1024-thread workgroup owns a tile of 16 envs for the whole network (256 workgroups at the benchmark's 4096
+// envs: every CU busy; 32-env tiles left half of the chip idle):
+//   traj tile (16 x 795) -> LDS -> [Dense+ReLU+LayerNorm] x len(encoder) -> fc2_mean | fc2_logvar (one pass)
+//   -> z = mean + eps * exp(logvar / 2) -> [z | (obs - mu) / sigma] -> decoder -> logits (16 x 60)
 //   -> scale = softplus(s) + 1e-3, raw = loc + scale * eps, action = tanh(raw), log_prob.
-// Every Dense is a sequence of v_mfma_f32_32x32x2_f32 (exact fp32, the reference's precision): the four
-// waves split the 32-column output tiles, A fragments come from LDS (odd leading dimension -> no bank
-// conflicts), B fragments stream from the L2-resident weight buffer (row-major (in, out), as Flax).
-// Activations never leave LDS; the only HBM traffic is the inputs, the weights and the outputs.
+// Every Dense is a sequence of v_mfma_f32_16x16x4_f32 (exact fp32, the reference's precision).  The sixteen waves
+// form a (64-column group) x (K slice) grid; A fragments come from LDS (leading dimension = 2 mod 32 -> the
+// ds_read_b32 is conflict-free), B fragments stream from the L2-resident weight buffer (row-major (in, out), as
+// Flax) with one dwordx4 per lane, two sets of four loads in flight per wave; the K slices' partial sums are added
+// in LDS in slice order.  Activations never leave LDS; the only HBM traffic is the inputs, the weights and the
+// outputs.  What bounds it: every workgroup streams all 1.36 MB of weights from L2 (347 MB per launch at 4096 envs,
+// ~20 us at the L2's ~17 TB/s) beside 17.6 us of MFMA issue per CU; measured phase times: tools/policy_stage_profile.py.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -19,11 +23,11 @@
 
 #include "../../include/vnl.h"
 
-#define PT 32          /* envs per workgroup */
+#define PT 16          /* envs per workgroup = rows of the 16x16x4 MFMA tile */
 #define PTHREADS 1024  /* 16 waves: four per SIMD, some compute while the others wait for their weight loads */
 #define LN_EPS 1e-6f   /* flax.linen.LayerNorm default */
 
-typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct PolicyDev {
   int traj_size, obs_size, act_size, latent;
@@ -33,57 +37,154 @@ struct PolicyDev {
   int enc_w[8], enc_b[8], enc_g[8], enc_be[8];
   int mean_w, mean_b, lv_w, lv_b;
   int dec_w[8], dec_b[8], dec_g[8], dec_be[8];
-  int ldA, ldB;  // leading dimensions (odd) of the two LDS activation buffers
+  int ldA, ldB;  // leading dimensions (= 2 mod 32: the A-fragment ds_read_b32 is conflict-free) of the two LDS activation buffers
 };
 
-// Y[32 x N] (LDS, ld = ldy) = X[32 x K] (LDS, ld = ldx) @ W[K x N] (global) + b, optional ReLU.
-// Wave w takes column tiles w, w+4, ...  Fragment layout of v_mfma_f32_32x32x2f32:
-//   A: lane l holds X[l % 32][k0 + l / 32];  B: lane l holds W[k0 + l / 32][n0 + l % 32];
-//   D: lane l, register i holds Y[(i / 4) * 8 + (l / 32) * 4 + i % 4][n0 + l % 32].
-__device__ __forceinline__ void dense_tile(const float* X, int ldx, int K, const float* __restrict__ W,
-                                           const float* __restrict__ bias, int N, float* Y, int ldy, bool relu) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = lane & 31, kh = lane >> 5;
-  const int ntiles = (N + 31) / 32;
-  for (int tile = wave; tile < ntiles; tile += PTHREADS / 64) {
-    const int col = tile * 32 + row;
-    const bool cok = col < N;
-    v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float* xr = X + row * ldx + kh;
-    const float* wc = W + (size_t)kh * N + (cok ? col : 0);
-    int k0 = 0;
-    for (; k0 + 16 <= K; k0 += 16) {  // 8 MFMAs per trip; the 8 weight loads are issued up front
-      float b[8], a[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) b[u] = cok ? wc[(size_t)(k0 + 2 * u) * N] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = xr[k0 + 2 * u];
-#pragma unroll
-      for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-    }
-    for (; k0 < K; k0 += 2) {
-      bool kok = k0 + kh < K;
-      float a = kok ? xr[k0] : 0.f;
-      float b = (kok && cok) ? wc[(size_t)k0 * N] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    if (cok) {
-      float bv = bias[col];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        int r = (i / 4) * 8 + kh * 4 + (i % 4);
-        float v = acc[i] + bv;
-        Y[r * ldy + col] = relu ? fmaxf(v, 0.f) : v;
-      }
-    }
-  }
+// Y[16 x N] (LDS, ld = ldy) = X[16 x K] (LDS, ld = ldx) @ W[K x N] (global, row-major) + b, optional ReLU.
+//
+// The sixteen waves form a (column group) x (K slice) grid: a wave owns 64 consecutive output columns -- four MFMA
+// tiles, tile t holding columns c0 + t of every lane's float4 -- so one global_load_dwordx4 per lane fetches four k-rows
+// of 256 contiguous bytes (whole cache lines; a 16-column tile per wave used half of every line it touched and was
+// bound by the L1's line rate).  With N = 256 that leaves 4 K slices, N = 128 -> 8, N <= 64 -> 16; the slices' partial
+// sums meet in P (LDS) and are added in slice order, bias first: deterministic.
+// Fragment layout of v_mfma_f32_16x16x4f32:  A: lane l holds X[l % 16][k0 + l / 16];  B: lane l holds
+// W[k0 + l / 16][column of l % 16];  D: lane l, register i holds Y[(l / 16) * 4 + i][column of l % 16].
+__device__ __forceinline__ int dense_col_groups(int N) {  // power of two <= 16 covering ceil(N / 64)
+  int G = (N + 63) >> 6, Gp = 1;
+  while (Gp < G && Gp < PTHREADS / 64) Gp <<= 1;
+  return Gp;
 }
 
-// in-place LayerNorm over the N columns of each of the 32 rows (wave w: rows 8w .. 8w+7)
+template <bool VEC>  // VEC: N % 4 == 0 and W 16-byte aligned -> one dwordx4 load per lane and k-row
+__device__ __forceinline__ void dense_tile_t(const float* X, int ldx, int K, const float* __restrict__ params, int w_off,
+                                             int b_off, int N, float* Y, int ldy, bool relu, float* P, int split,
+                                             int w2_off, int b2_off) {
+  const float* __restrict__ bias = params + b_off;
+  const float* __restrict__ bias2 = params + b2_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int G = (N + 63) >> 6, Gp = dense_col_groups(N), S = (PTHREADS / 64) / Gp;
+  const int g0 = wave & (Gp - 1), s = wave / Gp;
+  const int N4 = (N + 3) & ~3;
+  const int T = (K + 3) >> 2, Ts = (T + S - 1) / S;  // k-steps of 4, per slice
+  const int t0 = s * Ts, t1 = min(T, t0 + Ts);
+  const float* xr = X + j * ldx + kq;
+  // this thread's share of the bias (sum phase below), requested now so that its L2 latency passes under the MFMA loop
+  float bias_r[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = tid + q * PTHREADS;
+    const int c = e % N;
+    bias_r[q] = e < PT * N ? (c < split ? bias[c] : bias2[c - split]) : 0.f;
+  }
+  const int ldw = split < N ? split : N;  // row stride of the weight matrices
+  for (int g = g0; g < G; g += Gp) {
+    const int c0 = g * 64 + 4 * j;
+    // W[4 step + kq][c0 .. c0 + 3].  Outside the slice / the matrix the address is clamped to valid weights and the
+    // A operand is zeroed instead (no select on the loaded value: it would pin the wait right behind the load);
+    // columns >= N compute garbage that is never read back.
+    auto load_b = [&](int step) -> v4f {
+      const int k = 4 * step + kq;
+      const float* w = params + (c0 < split ? w_off : w2_off - split) + (size_t)((step < t1 && k < K) ? k : 0) * ldw;
+      v4f b;
+      if (VEC) {
+        b = *(const v4f*)(w + (c0 < N ? c0 : 0));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) b[t] = w[c0 + t < N ? c0 + t : 0];
+      }
+      return b;
+    };
+    v4f acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    // four k-steps (16 MFMAs) on the weights in b, A fragments from LDS
+    auto mma4 = [&](const v4f (&b)[4], int t) {
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int step = t + u;
+        const bool ok = step < t1 && 4 * step + kq < K;  // columns of X past K hold stale activations
+        float v = xr[ok ? 4 * step : 0];
+        a[u] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][tt], acc[tt], 0, 0, 0);
+    };
+    // ping-pong weight registers (no copies: a copy of a prefetched value would pin the wait for it at the loop's end):
+    // the MFMAs on one set run under the loads of the other
+    v4f b0[4], b1[4];
+    if (t0 < t1) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) b0[u] = load_b(t0 + u);
+    }
+    for (int t = t0; t < t1; t += 8) {  // the conditions are wave-uniform; no load is issued for nothing
+      const bool more1 = t + 4 < t1, more0 = t + 8 < t1;
+      if (more1) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) b1[u] = load_b(t + 4 + u);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the MFMAs they are to run under
+      mma4(b0, t);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) b0[u] = load_b(t + 8 + u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) mma4(b1, t + 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c0 < N4) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        *(v4f*)(P + (size_t)(s * PT + kq * 4 + i) * N4 + c0) = v4f{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+    }
+  }
+  __syncthreads();
+  auto finish = [&](int e, float v) {
+    const int r = e / N, c = e - r * N;
+    for (int ss = 0; ss < S; ss++) v += P[(size_t)(ss * PT + r) * N4 + c];
+    Y[r * ldy + c] = relu ? fmaxf(v, 0.f) : v;
+  };
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = tid + q * PTHREADS;
+    if (e < PT * N) finish(e, bias_r[q]);
+  }
+  for (int e = tid + 4 * PTHREADS; e < PT * N; e += PTHREADS) finish(e, e % N < split ? bias[e % N] : bias2[e % N - split]);
+  __syncthreads();
+}
+
+// Weights and biases are addressed as offsets into the flat parameter vector.
+// `split` < N: columns [split, N) come from a second Dense (w2_off, b2_off) of the same input -- the two latent heads run as
+// one pass; needs split % 64 == 0 (a column group reads one matrix) and N == 2 * split (one row stride).
+__device__ __forceinline__ void dense_tile(const float* X, int ldx, int K, const float* __restrict__ params, int w_off,
+                                           int b_off, int N, float* Y, int ldy, bool relu, float* P, int split = 1 << 30,
+                                           int w2_off = 0, int b2_off = 0) {
+  // branch once, outside the pipelined loop: control flow between the prefetch loads and the MFMAs makes the compiler
+  // wait for every outstanding load (s_waitcnt vmcnt(0)) before the first MFMA of a trip
+  const int ldw = split < N ? split : N;
+  if ((ldw & 3) == 0 && ((uintptr_t)params & 15) == 0 && (w_off & 3) == 0 && (w2_off & 3) == 0)
+    dense_tile_t<true>(X, ldx, K, params, w_off, b_off, N, Y, ldy, relu, P, split, w2_off, b2_off);
+  else
+    dense_tile_t<false>(X, ldx, K, params, w_off, b_off, N, Y, ldy, relu, P, split, w2_off, b2_off);
+}
+
+// in-place LayerNorm over the N columns of each of the PT rows (one row per wave)
 __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const float* __restrict__ g,
                                                 const float* __restrict__ be) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPW = PT / (PTHREADS / 64);  // rows per wave
+  // scale / bias of the first 256 columns are requested before the row statistics (their latency passes under them)
+  float gr[4], br[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c = lane + 64 * q;
+    gr[q] = c < N ? g[c] : 0.f, br[q] = c < N ? be[c] : 0.f;
+  }
   for (int r = wave * RPW; r < wave * RPW + RPW; r++) {
     float* y = Y + r * ldy;
     float s = 0.f, ss = 0.f;
@@ -95,9 +196,67 @@ __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const 
     float mean = s / (float)N;
     float var = fmaxf(ss / (float)N - mean * mean, 0.f);
     float inv = rsqrtf(var + LN_EPS);
-    for (int c = lane; c < N; c += 64) y[c] = (y[c] - mean) * inv * g[c] + be[c];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = lane + 64 * q;
+      if (c < N) y[c] = (y[c] - mean) * inv * gr[q] + br[q];
+    }
+    for (int c = lane + 256; c < N; c += 64) y[c] = (y[c] - mean) * inv * g[c] + be[c];
   }
 }
+
+// dst[r][c] (LDS, ld) = src[r * width + c] for r < nrow, 0 for nrow <= r < PT; optionally (v - mean[c]) / std[c].
+// src is the tile's contiguous chunk of PT * width floats; float4 loads, four per thread in flight, when it is 16-byte
+// aligned (a load -> LDS store loop of scalars costs one HBM latency per trip: 13 trips for the traj tile).
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int nrow, int width, float* dst, int ld,
+                                          const float* __restrict__ mean, const float* __restrict__ stdv) {
+  const int tid = threadIdx.x, n = nrow * width;
+  auto put = [&](int i, float v) {
+    const int r = i / width, c = i - r * width;
+    if (mean) v = (v - mean[c]) / stdv[c];
+    dst[r * ld + c] = v;
+  };
+  int done = 0;
+  if (((uintptr_t)src & 15) == 0) {
+    const v4f* s4 = (const v4f*)src;
+    const int n4 = n >> 2;
+    for (int base = 0; base < n4; base += 4 * PTHREADS) {
+      v4f v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * PTHREADS + tid;
+        v[u] = s4[i < n4 ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * PTHREADS + tid;
+        if (i < n4) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) put(4 * i + q, v[u][q]);
+        }
+      }
+    }
+    done = n4 << 2;
+  }
+  for (int i = done + tid; i < n; i += PTHREADS) put(i, src[i]);
+  for (int i = n + tid; i < PT * width; i += PTHREADS) {
+    const int r = i / width, c = i - r * width;
+    dst[r * ld + c] = 0.f;
+  }
+}
+
+#ifdef VNL_PROFILE  // prof variant only: wall-clock (100 MHz) stamps of workgroup 0 at the phase boundaries
+__device__ long long g_policy_stamps[32];
+#define POL_STAMP(i)                                                               \
+  do {                                                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_policy_stamps[i] = wall_clock64(); \
+  } while (0)
+extern "C" int vnl_policy_profile_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_policy_stamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
+}
+#else
+#define POL_STAMP(i)
+#endif
 
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
@@ -116,23 +275,24 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
   extern __shared__ __align__(16) float lds[];
   float* A = lds;
   float* B = lds + PT * p.ldA;
+  float* P = B + PT * p.ldB;  // K-slice partial sums of the Dense in flight
   const int e0 = blockIdx.x * PT, tid = threadIdx.x;
   const int nrow = min(PT, batch - e0);
 
-  // traj tile -> A (rows beyond the batch are zero)
-  for (int i = tid; i < PT * p.traj_size; i += PTHREADS) {
-    int r = i / p.traj_size, c = i - r * p.traj_size;
-    A[r * p.ldA + c] = r < nrow ? traj[(size_t)(e0 + r) * p.traj_size + c] : 0.f;
-  }
+  POL_STAMP(0);
+  // traj tile -> A (rows beyond the batch are zero).  The tile's rows are one contiguous chunk of the input.
+  load_tile(traj + (size_t)e0 * p.traj_size, nrow, p.traj_size, A, p.ldA, nullptr, nullptr);
   __syncthreads();
+  POL_STAMP(1);
   // ---- encoder: Dense -> ReLU -> LayerNorm   (intention_policy_network.py:29-41)
   float *X = A, *Y = B;
   int ldx = p.ldA, ldy = p.ldB, K = p.traj_size;
   for (int l = 0; l < p.n_enc; l++) {
-    dense_tile(X, ldx, K, params + p.enc_w[l], params + p.enc_b[l], p.enc[l], Y, ldy, true);
-    __syncthreads();
+    dense_tile(X, ldx, K, params, p.enc_w[l], p.enc_b[l], p.enc[l], Y, ldy, true, P);
+    POL_STAMP(2 + 2 * l);
     layer_norm_rows(Y, ldy, p.enc[l], params + p.enc_g[l], params + p.enc_be[l]);
     __syncthreads();
+    POL_STAMP(3 + 2 * l);
     float* t = X;
     X = Y, Y = t;
     int tl = ldx;
@@ -140,9 +300,13 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     K = p.enc[l];
   }
   // ---- heads (ipn:42-44): mean -> Y[:, 0:latent], logvar -> Y[:, latent:2 latent]
-  dense_tile(X, ldx, K, params + p.mean_w, params + p.mean_b, p.latent, Y, ldy, false);
-  dense_tile(X, ldx, K, params + p.lv_w, params + p.lv_b, p.latent, Y + p.latent, ldy, false);
-  __syncthreads();
+  if ((p.latent & 63) == 0) {
+    dense_tile(X, ldx, K, params, p.mean_w, p.mean_b, 2 * p.latent, Y, ldy, false, P, p.latent, p.lv_w, p.lv_b);
+  } else {
+    dense_tile(X, ldx, K, params, p.mean_w, p.mean_b, p.latent, Y, ldy, false, P);
+    dense_tile(X, ldx, K, params, p.lv_w, p.lv_b, p.latent, Y + p.latent, ldy, false, P);
+  }
+  POL_STAMP(10);
   // ---- z = mean + eps * exp(logvar / 2) (ipn:73-76); decoder input [z | normalised obs] -> X
   for (int i = tid; i < PT * p.latent; i += PTHREADS) {
     int r = i / p.latent, c = i - r * p.latent;
@@ -155,22 +319,16 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     }
     X[r * ldx + c] = z;
   }
-  for (int i = tid; i < PT * p.obs_size; i += PTHREADS) {
-    int r = i / p.obs_size, c = i - r * p.obs_size;
-    float v = 0.f;
-    if (r < nrow) {
-      v = obs[(size_t)(e0 + r) * p.obs_size + c];
-      if (obs_mean) v = (v - obs_mean[c]) / obs_std[c];  // running_statistics.normalize; traj is NOT normalised
-    }
-    X[r * ldx + p.latent + c] = v;
-  }
+  // normalised obs (running_statistics.normalize; traj is NOT normalised)
+  load_tile(obs + (size_t)e0 * p.obs_size, nrow, p.obs_size, X + p.latent, ldx, obs_mean, obs_std);
   __syncthreads();
+  POL_STAMP(11);
   // ---- decoder (ipn:56-70): [Dense -> ReLU -> LayerNorm] x (n-1), last Dense linear
   K = p.latent + p.obs_size;
   for (int l = 0; l < p.n_dec; l++) {
     bool last = l == p.n_dec - 1;
-    dense_tile(X, ldx, K, params + p.dec_w[l], params + p.dec_b[l], p.dec[l], Y, ldy, !last);
-    __syncthreads();
+    dense_tile(X, ldx, K, params, p.dec_w[l], p.dec_b[l], p.dec[l], Y, ldy, !last, P);
+    POL_STAMP(12 + 2 * l);
     if (!last) {
       layer_norm_rows(Y, ldy, p.dec[l], params + p.dec_g[l], params + p.dec_be[l]);
       __syncthreads();
@@ -181,6 +339,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     ldx = ldy, ldy = tl;
     K = p.dec[l];
   }
+  POL_STAMP(20);
   // ---- distribution (brax NormalTanhDistribution; ppo_networks.py:56-83): X holds logits [loc | s]
   const int na = p.act_size;
   for (int i = tid; i < PT * 2 * na; i += PTHREADS) {
@@ -222,6 +381,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
       rand_log_prob[e0 + tid] = s2;
     }
   }
+  POL_STAMP(21);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -298,11 +458,35 @@ extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, in
   wide = wide > d.latent + d.obs_size ? wide : d.latent + d.obs_size;
   wide = wide > 2 * d.latent ? wide : 2 * d.latent;
   int la = d.traj_size > wide ? d.traj_size : wide;
-  d.ldA = la | 1, d.ldB = wide | 1;
-  p->lds_bytes = (size_t)PT * (d.ldA + d.ldB) * sizeof(float);
+  // ds_read_b32 banks are (address / 4) % 32 per 32-lane half; a half reads rows 0..15 x two k: ld = 2 mod 32 -> 32 banks
+  auto pad = [](int w) { return ((w + 29) / 32) * 32 + 2; };
+  d.ldA = pad(la), d.ldB = pad(wide);
+  // partial sums of the widest Dense: (K slices) x 16 rows x N; slices x N <= 1024 whenever N <= 1024
+  int pw = 0;
+  auto part = [&](int n) {
+    int G = (n + 63) / 64, Gp = 1;
+    while (Gp < G && Gp < PTHREADS / 64) Gp <<= 1;
+    int w = (PTHREADS / 64 / Gp) * ((n + 3) & ~3);
+    if (G > Gp) w = -1;  // a wave would loop over column groups with one slice: needs N <= 1024
+    return w;
+  };
+  bool too_wide = false;
+  auto upd = [&](int n) {
+    int w = part(n);
+    if (w < 0) too_wide = true;
+    pw = w > pw ? w : pw;
+  };
+  for (int l = 0; l < d.n_enc; l++) upd(d.enc[l]);
+  for (int l = 0; l < d.n_dec; l++) upd(d.dec[l]);
+  upd(d.latent), upd(2 * d.latent);
+  if (too_wide) {
+    delete p;
+    return pfail(VNL_ERR_UNSUPPORTED, "layers wider than 1024 are not supported by the fused policy kernel");
+  }
+  p->lds_bytes = (size_t)PT * (d.ldA + d.ldB + pw) * sizeof(float);
   if (p->lds_bytes > 160 * 1024 - 512) {
     delete p;
-    return pfail(VNL_ERR_UNSUPPORTED, "network too wide for the 32-env LDS tile");
+    return pfail(VNL_ERR_UNSUPPORTED, "network too wide for the 16-env LDS tile");
   }
   p->device = device, p->max_batch = max_batch;
   if (p->lds_bytes > 64 * 1024) {
