@@ -25,5 +25,4 @@ def test_two_rank_training_keeps_replicas_identical():
         assert r["identical"]
         # normaliser saw the GLOBAL batch: 2 training steps x 8 envs x 4 steps
         assert r["count"] == 2 * 8 * 4
-        # per training step: 3 normaliser all-reduces + num_updates(2) x num_minibatches(2) gradient all-reduces
-        assert r["allreduce"] == 2 * (3 + 2 * 2)
+        assert r["allreduce"] == 2 * (2 + 2 * 2)  # per training step: 2 normaliser + updates x minibatches gradient

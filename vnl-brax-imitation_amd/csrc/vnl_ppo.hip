@@ -51,7 +51,7 @@ enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SWISH = 2, EPI_MUL_DSWISH = 3 };
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <int BM, int BN, bool TA, bool TB, int EPI>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
   // K depth of a staged slab: 32 for the 64 x 64 tile (1024 MFMA cycles per wave and slab cover the global-load latency of
   // the next one; 35 KB of LDS), 16 for the 128 x 128 tile (2048 cycles, 34 KB)
   constexpr int BK = BM == 64 ? 32 : 16, LDA = BM + 4, LDB = BN + 4;
@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   __shared__ __align__(16) float As[2][BK][LDA];
   __shared__ __align__(16) float Bs[2][BK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
-  float* C = g.C + (size_t)blockIdx.z * g.slab_stride;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  float* C = g.C + (size_t)bz * g.slab_stride;
 
   f32x16 acc[MI][NJ];
 #pragma unroll
@@ -225,6 +225,30 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+template <int BM, int BN, bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+  gemm_body<BM, BN, TA, TB, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent GEMMs of one flavour as ONE launch (the seven small weight gradients of the intention network:
+// 20 us each on their own, latency-bound at 50-100 workgroups; together they fill the chip).  Workgroup b of the launch
+// is tile (b - first[j]) of problem j; the tile's (x, y, z) follow the grid of a stand-alone launch.
+#define VNL_MAX_GROUP 8
+struct GemmGroup {
+  int n;
+  int first[VNL_MAX_GROUP + 1];  // prefix sums of the problems' workgroup counts
+  int gx[VNL_MAX_GROUP], gy[VNL_MAX_GROUP];
+  GemmArgs g[VNL_MAX_GROUP];
+};
+template <int BM, int BN, bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(256) gemm_group_kernel(GemmGroup grp) {
+  int j = 0;
+  while (j + 1 < grp.n && (int)blockIdx.x >= grp.first[j + 1]) j++;
+  const int t = blockIdx.x - grp.first[j], gx = grp.gx[j], gy = grp.gy[j];
+  const int bz = t / (gx * gy), r = t - bz * gx * gy;
+  gemm_body<BM, BN, TA, TB, EPI>(grp.g[j], r % gx, r / gx, bz);
+}
+
 // out[i] = sum_s part[s * stride + i]   (fixed order: deterministic)
 __global__ void __launch_bounds__(256) sum_slabs_kernel(float* out, const float* part, int S, size_t stride, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -295,9 +319,19 @@ struct SlabPool {  // host-side bump allocator over the slab buffer + the list o
   int tile;  // 0: by shape, 64 / 128: forced (tuning knob of tools/ppo_update_bench.py)
 };
 
+static void launch_wgrad_group(hipStream_t st, GemmGroup& grp) {
+  if (grp.n == 0) return;
+  hipLaunchKernelGGL((gemm_group_kernel<64, 64, true, false, EPI_NONE>), dim3(grp.first[grp.n]), dim3(256), 0, st, grp);
+  grp.n = 0;
+}
+
 struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
   hipStream_t st;
   SlabPool* pool;
+  GemmGroup* group = nullptr;  // non-null: 64 x 64 weight gradients are collected here and launched together by flush()
+  void flush() {
+    if (group) launch_wgrad_group(st, *group);
+  }
   void run(bool TA, bool TB, int epi, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
            const float* bias = nullptr, const float* aux = nullptr, int ldaux = 0, float* zout = nullptr, int accumulate = 0) {
     GemmArgs g{A, B, C, bias, aux, zout, nullptr, M, N, K, lda, ldb, ldc, ldaux, K, accumulate, 0, 0, 0, 1, 0};
@@ -334,8 +368,18 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
       g.k_chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
       pool->used += splits * tot;
     }
-    if (big) launch_gemm_cfg<128, 128>(st, true, false, EPI_NONE, g, splits);
-    else launch_gemm_cfg<64, 64>(st, true, false, EPI_NONE, g, splits);
+    if (big) {
+      launch_gemm_cfg<128, 128>(st, true, false, EPI_NONE, g, splits);
+    } else if (group) {
+      if (group->n == VNL_MAX_GROUP) flush();
+      const int j = group->n++;
+      if (j == 0) group->first[0] = 0;
+      group->gx[j] = (N + 63) / 64, group->gy[j] = (M + 63) / 64;
+      group->first[j + 1] = group->first[j] + group->gx[j] * group->gy[j] * splits;
+      group->g[j] = g;
+    } else {
+      launch_gemm_cfg<64, 64>(st, true, false, EPI_NONE, g, splits);
+    }
   }
 };
 
@@ -360,34 +404,60 @@ __global__ void __launch_bounds__(256) prep_kernel(const float* obs, const float
   }
 }
 
-// LayerNorm forward (flax eps 1e-6) over rows of H (already ReLU'd): one wave per row
+// LayerNorm forward (flax eps 1e-6) over rows of H (already ReLU'd): one wave per row, the row held in registers
+// (h <= 64 PER; one pass over memory, every load of a wave in flight at once)
+template <int PER>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* H, const float* gamma, const float* beta, float* Y, float* stats,
                                                      int rows, int h) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float gm[PER], bt[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int c = lane + 64 * k;
+    gm[k] = c < h ? gamma[c] : 0.f, bt[k] = c < h ? beta[c] : 0.f;
+  }
   for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
     const float* x = H + (size_t)r * h;
-    float s = 0.f;
-    for (int c = lane; c < h; c += 64) s += x[c];
+    float xv[PER], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int c = lane + 64 * k;
+      xv[k] = c < h ? x[c] : 0.f;
+      s += xv[k];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s / (float)h;
     float q = 0.f;
-    for (int c = lane; c < h; c += 64) {
-      const float d = x[c] - mu;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const float d = lane + 64 * k < h ? xv[k] - mu : 0.f;
       q += d * d;
     }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q / (float)h + 1e-6f);
-    for (int c = lane; c < h; c += 64) Y[(size_t)r * h + c] = (x[c] - mu) * rstd * gamma[c] + beta[c];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int c = lane + 64 * k;
+      if (c < h) Y[(size_t)r * h + c] = (xv[k] - mu) * rstd * gm[k] + bt[k];
+    }
     if (lane == 0) stats[2 * r] = mu, stats[2 * r + 1] = rstd;
   }
 }
+static void ln_fwd(hipStream_t st, const float* H, const float* gamma, const float* beta, float* Y, float* stats, int rows, int h) {
+  const int blocks = (rows + 3) / 4;  // one row per wave
+  if (h <= 128) hipLaunchKernelGGL((ln_fwd_kernel<2>), dim3(blocks), dim3(256), 0, st, H, gamma, beta, Y, stats, rows, h);
+  else if (h <= 256) hipLaunchKernelGGL((ln_fwd_kernel<4>), dim3(blocks), dim3(256), 0, st, H, gamma, beta, Y, stats, rows, h);
+  else hipLaunchKernelGGL((ln_fwd_kernel<16>), dim3(blocks), dim3(256), 0, st, H, gamma, beta, Y, stats, rows, h);
+}
 
 // LayerNorm + ReLU backward: dZ = relu'(H) * LN'(dY); per-block partial sums of d gamma, d beta -> part[blk][2][h]
-template <int HMAX>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* dY, const float* H, const float* stats, const float* gamma, float* dZ,
-                                                     float* part, int rows, int h, int part_stride) {
+// (NW waves per block: sixteen for h <= 256 -- 80 blocks x 16 waves leave two rows per wave, so the rows' load -> reduce ->
+// store chains run side by side instead of ten deep)
+template <int HMAX, int NW>
+__global__ void __launch_bounds__(64 * NW) ln_bwd_kernel(const float* dY, const float* H, const float* stats, const float* gamma,
+                                                         float* dZ, float* part, int rows, int h, int part_stride) {
   constexpr int PER = HMAX / 64;
-  __shared__ float red[4][2][HMAX];
+  __shared__ float red[NW][2][HMAX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float dg[PER], db[PER], gm[PER];
 #pragma unroll
@@ -396,7 +466,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* dY, const floa
     const int c = lane + 64 * k;
     gm[k] = c < h ? gamma[c] : 0.f;
   }
-  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * NW + w; r < rows; r += gridDim.x * NW) {
     const float mu = stats[2 * r], rstd = stats[2 * r + 1];
     float xh[PER], gy[PER], hv[PER], s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -421,9 +491,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* dY, const floa
 #pragma unroll
   for (int k = 0; k < PER; k++) red[w][0][lane + 64 * k] = dg[k], red[w][1][lane + 64 * k] = db[k];
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * h; c += 256) {
+  for (int c = threadIdx.x; c < 2 * h; c += 64 * NW) {
     const int which = c / h, cc = c % h;
-    part[(size_t)blockIdx.x * part_stride + (size_t)which * h + cc] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; q++) a += red[q][which][cc];
+    part[(size_t)blockIdx.x * part_stride + (size_t)which * h + cc] = a;
   }
 }
 
@@ -509,6 +582,9 @@ struct vnl_ppo_update {
   float *obsn = nullptr, *trajp = nullptr, *D0 = nullptr, *ml = nullptr, *mean = nullptr, *logvar = nullptr, *logits = nullptr;
   float *v = nullptr, *gl = nullptr, *gb = nullptr, *gklm = nullptr, *gkll = nullptr, *vs = nullptr, *adv = nullptr, *headws = nullptr;
   float *dml = nullptr, *dA = nullptr, *dB = nullptr, *dPa = nullptr, *dPb = nullptr, *slabs = nullptr, *part = nullptr;
+  float* dzarena = nullptr;  // d loss / d (pre-activations) of every LayerNorm layer: each keeps its own buffer until the
+                             // step's grouped weight-gradient launch has read it
+  size_t dz_floats = 0;
   hipStream_t s2 = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int tile = 0;
@@ -630,6 +706,9 @@ extern "C" int vnl_ppo_update_create(const vnl_ppo_net_spec* sp, int32_t T, int3
   AL(u->dB, Nv * wmax);
   AL(u->dPa, N * wmax);
   AL(u->dPb, N * wmax);
+  for (auto& d : u->enc) u->dz_floats += N * d.out;
+  for (auto& d : u->dec) u->dz_floats += N * d.out;
+  AL(u->dzarena, u->dz_floats);
   for (auto& d : u->enc) {
     float *h = nullptr, *y = nullptr, *s = nullptr;
     AL(h, N * d.out);
@@ -673,7 +752,7 @@ extern "C" int vnl_ppo_update_create(const vnl_ppo_net_spec* sp, int32_t T, int3
 // scale then bias) go to a slab region of their own and are summed by the step's final reduce_jobs launch
 static void ln_bwd(vnl_ppo_update* u, SlabPool* pool, hipStream_t st, const float* dY, const float* H, const float* stats,
                    const float* gamma, float* dZ, float* dgamma, int rows, int h) {
-  const int blocks = 64;
+  const int blocks = h <= 256 ? 80 : 64;
   const size_t tot = ((size_t)2 * h + 3) & ~(size_t)3;
   float* part = u->part;
   bool deferred = false;
@@ -687,9 +766,9 @@ static void ln_bwd(vnl_ppo_update* u, SlabPool* pool, hipStream_t st, const floa
     pool->used += blocks * tot;
     deferred = true;
   }
-  if (h <= 128) hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3(blocks), dim3(256), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
-  else if (h <= 256) hipLaunchKernelGGL((ln_bwd_kernel<256>), dim3(blocks), dim3(256), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
-  else hipLaunchKernelGGL((ln_bwd_kernel<1024>), dim3(blocks), dim3(256), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
+  if (h <= 128) hipLaunchKernelGGL((ln_bwd_kernel<128, 16>), dim3(blocks), dim3(1024), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
+  else if (h <= 256) hipLaunchKernelGGL((ln_bwd_kernel<256, 16>), dim3(blocks), dim3(1024), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
+  else hipLaunchKernelGGL((ln_bwd_kernel<1024, 4>), dim3(blocks), dim3(256), 0, st, dY, H, stats, gamma, dZ, part, rows, h, (int)tot);
   if (!deferred)
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((2 * h + 255) / 256), dim3(256), 0, st, dgamma, (const float*)part, blocks, tot,
                        (size_t)2 * h);
@@ -714,7 +793,15 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   const int N = u->N, Nv = u->Nv, no = sp.obs_size, lat = sp.latent_size, A2 = 2 * sp.action_size;
   SlabPool pool{u->slabs, u->slab_floats, 0, {}, u->tile};
   pool.jobs.njobs = 0, pool.jobs.start4[0] = 0;
-  Gemm GV{st, &pool}, GP{sp2, &pool};
+  GemmGroup group;
+  group.n = 0;
+  Gemm GV{st, &pool}, GP{sp2, &pool, &group};
+  size_t dz_used = 0;
+  auto dz_alloc = [&](size_t n) {  // (sized in create for every layer's N x out: cannot run out)
+    float* q = u->dzarena + dz_used;
+    dz_used += n;
+    return q;
+  };
   const float* P = params;
   float* Gr = grads;
 
@@ -746,8 +833,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     for (size_t i = 0; i < u->enc.size(); i++) {
       const DenseP& d = u->enc[i];
       GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->encH[i], d.out, N, d.out, d.in, P + d.b);
-      hipLaunchKernelGGL(ln_fwd_kernel, dim3(256), dim3(256), 0, sp2, (const float*)u->encH[i], P + d.g, P + d.be, u->encY[i],
-                         u->encS[i], N, d.out);
+      ln_fwd(sp2, u->encH[i], P + d.g, P + d.be, u->encY[i], u->encS[i], N, d.out);
       x = u->encY[i], ldx = d.out;
     }
     const int fan = u->enc.back().out;
@@ -766,8 +852,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
       const DenseP& d = u->dec[i];
       if (d.ln) {
         GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->decH[i], d.out, N, d.out, d.in, P + d.b);
-        hipLaunchKernelGGL(ln_fwd_kernel, dim3(256), dim3(256), 0, sp2, (const float*)u->decH[i], P + d.g, P + d.be, u->decY[i],
-                           u->decS[i], N, d.out);
+        ln_fwd(sp2, u->decH[i], P + d.g, P + d.be, u->decY[i], u->decS[i], N, d.out);
         x = u->decY[i], ldx = d.out;
       } else {
         GP.run(false, false, EPI_NONE, x, ldx, P + d.w, d.out, u->logits, d.out, N, d.out, d.in, P + d.b);
@@ -817,8 +902,10 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   }
   // ---------------- backward: decoder, latent, encoder (second stream)
   {
-    float *dcur = u->dPa, *dnext = u->dPb;  // dcur: d loss / d (a layer's input); dnext: d loss / d (pre-activations)
-    const float* dz = u->gl;                // d loss / d logits [N][2 act]
+    // The chain of input gradients runs first, launch after launch; the layers' weight gradients [X | 1]' dZ are only
+    // collected (GP.wgrad defers them) and run as one grouped launch at the end, so every dZ keeps a buffer of its own.
+    float* dcur = u->dPa;     // d loss / d (a layer's input), consumed by the next launch
+    const float* dz = u->gl;  // d loss / d logits [N][2 act]
     int dzw = A2;
     for (int i = (int)u->dec.size() - 1; i >= 0; i--) {
       const DenseP& d = u->dec[i];
@@ -830,8 +917,9 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
       GP.run(false, true, EPI_NONE, dz, dzw, P + d.w, d.out, dcur, nin, N, nin, d.out);
       if (i > 0) {
         const DenseP& pd = u->dec[i - 1];
+        float* dnext = dz_alloc((size_t)N * pd.out);
         ln_bwd(u, &pool, sp2, dcur, u->decH[i - 1], u->decS[i - 1], P + pd.g, dnext, Gr + pd.g, N, pd.out);
-        dz = dnext, dzw = pd.out;  // (the old dz is dead once this layer's three launches are queued)
+        dz = dnext, dzw = pd.out;
       }
     }
     // dcur = d loss / d z  [N][lat]
@@ -841,18 +929,19 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     const float* ylast = u->encY.back();
     GP.wgrad(ylast, le.out, u->dml, 2 * lat, Gr + u->mean_w, Gr + u->mean_b, le.out, lat, N);
     GP.wgrad(ylast, le.out, u->dml + lat, 2 * lat, Gr + u->lv_w, Gr + u->lv_b, le.out, lat, N);
-    float* dy = dnext;  // d loss / d (last encoder output) = dmean Wm' + dlogvar Wlv'
+    float* dy = u->dPb;  // d loss / d (last encoder output) = dmean Wm' + dlogvar Wlv'
     GP.run(false, true, EPI_NONE, u->dml, 2 * lat, P + u->mean_w, lat, dy, le.out, N, le.out, lat);
     GP.run(false, true, EPI_NONE, u->dml + lat, 2 * lat, P + u->lv_w, lat, dy, le.out, N, le.out, lat, nullptr, nullptr, 0, nullptr, 1);
-    float* other = dcur;
     for (int i = (int)u->enc.size() - 1; i >= 0; i--) {
       const DenseP& d = u->enc[i];
-      ln_bwd(u, &pool, sp2, dy, u->encH[i], u->encS[i], P + d.g, other, Gr + d.g, N, d.out);  // other = dZ_i
+      float* dzi = dz_alloc((size_t)N * d.out);
+      ln_bwd(u, &pool, sp2, dy, u->encH[i], u->encS[i], P + d.g, dzi, Gr + d.g, N, d.out);
       const float* xin = i > 0 ? u->encY[i - 1] : u->trajp;
       const int ldx = i > 0 ? u->enc[i - 1].out : u->ntp;
-      GP.wgrad(xin, ldx, other, d.out, Gr + d.w, Gr + d.b, d.in, d.out, N);
-      if (i > 0) GP.run(false, true, EPI_NONE, other, d.out, P + d.w, d.out, dy, d.in, N, d.in, d.out);
+      GP.wgrad(xin, ldx, dzi, d.out, Gr + d.w, Gr + d.b, d.in, d.out, N);
+      if (i > 0) GP.run(false, true, EPI_NONE, dzi, d.out, P + d.w, d.out, dy, d.in, N, d.in, d.out);
     }
+    GP.flush();  // every weight gradient of the intention network: one grouped launch
   }
   PCHK(hipEventRecord(u->ev[3], sp2));
   PCHK(hipStreamWaitEvent(st, u->ev[3], 0));

@@ -115,6 +115,9 @@ class RodentTracking(Env):
     _use_clip_com = False
 
     def _build(self, reference_clip, num_envs, device, _library, _dtype):
+        # everything set so far is configuration; what follows is per-instance device state (with_num_envs)
+        self._config_attrs = dict(self.__dict__)
+        self._build_args = (reference_clip, device, _library, _dtype)
         m = self.sys
         healthy_z_range = self._healthy_z_range
         # --- clip (rodent.py:112-115): filter body_positions to the tracked bodies -----
@@ -175,6 +178,14 @@ class RodentTracking(Env):
         _lib.check(self._L, self._L.vnl_env_dims(self._env_h, C.byref(self.dims)))
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(0)
+
+    def with_num_envs(self, num_envs: int) -> "RodentTracking":
+        """A second env of the same configuration (model, clip, reward parameters) with its own batch of `num_envs`
+        envs on the device -- the evaluator's env when num_eval_envs differs from the training batch."""
+        new = object.__new__(type(self))
+        new.__dict__.update(self._config_attrs)
+        new._build(self._build_args[0], int(num_envs), *self._build_args[1:])
+        return new
 
     def __del__(self):
         try:

@@ -32,18 +32,18 @@ def init_state(size: int, device=None) -> RunningStatisticsState:
 
 def update(state: RunningStatisticsState, batch: torch.Tensor, *, std_min_value: float = 1e-6,
            std_max_value: float = 1e6, process_group=None, distributed: bool = False) -> RunningStatisticsState:
+    """Welford-style update of brax.training.acme.running_statistics.update.  Data-parallel: TWO all-reduces per call --
+    [count | sum of (x - old mean)] in one buffer, then the sum of (x - old mean)(x - new mean), which needs the new,
+    global, mean (the same two dependent psums as brax)."""
     x = batch.reshape(-1, batch.shape[-1])
-    n = torch.tensor(float(x.shape[0]), dtype=torch.float32, device=x.device)
+    diff_old = x - state.mean
+    packed = torch.cat([torch.full((1,), float(x.shape[0]), dtype=torch.float32, device=x.device), diff_old.sum(0)])
     if distributed:
         import torch.distributed as dist
 
-        dist.all_reduce(n, group=process_group)
-    count = state.count + n
-    diff_old = x - state.mean
-    s1 = diff_old.sum(0)
-    if distributed:
-        dist.all_reduce(s1, group=process_group)
-    mean = state.mean + s1 / count
+        dist.all_reduce(packed, group=process_group)
+    count = state.count + packed[0]
+    mean = state.mean + packed[1:] / count
     s2 = (diff_old * (x - mean)).sum(0)
     if distributed:
         dist.all_reduce(s2, group=process_group)

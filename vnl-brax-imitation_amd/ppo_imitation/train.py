@@ -428,10 +428,16 @@ def train(
         eval_env = environment
     evaluator = None
     if rank == 0 and eval_env is not None and num_eval_envs > 0:
+        # num_eval_envs is honoured (train.py:433-441 resets the eval env with that many keys): the device env has a fixed
+        # batch, so a different count gets an env of its own with the same configuration
+        if eval_env.unwrapped.num_envs != num_eval_envs:
+            if not hasattr(eval_env.unwrapped, "with_num_envs"):
+                raise ValueError(f"eval_env has {eval_env.unwrapped.num_envs} envs, num_eval_envs = {num_eval_envs}")
+            eval_env = eval_env.unwrapped.with_num_envs(num_eval_envs)
         ev_wrapped = env_wrappers.wrap(eval_env, episode_length=episode_length, action_repeat=action_repeat,
                                        reset_info_on_autoreset=reset_info_on_autoreset)
         evaluator = acting.Evaluator(ev_wrapped, functools.partial(make_policy, deterministic=deterministic_eval),
-                                     num_eval_envs=eval_env.unwrapped.num_envs, episode_length=episode_length,
+                                     num_eval_envs=num_eval_envs, episode_length=episode_length,
                                      action_repeat=action_repeat, key=g_eval)
 
     def inference_params():
@@ -442,8 +448,6 @@ def train(
         metrics = evaluator.run_evaluation(inference_params(), training_metrics={})
         logging.info(metrics)
         progress_fn(0, metrics)
-        if eval_env is environment:
-            env_state = env.reset(g_env)
 
     training_metrics: Metrics = {}
     current_step = 0
@@ -457,9 +461,8 @@ def train(
         if rank == 0:
             metrics = training_metrics
             if evaluator is not None:
-                metrics = evaluator.run_evaluation(inference_params(), training_metrics)
-                if eval_env is environment:
-                    env_state = env.reset(g_env)
+                metrics = evaluator.run_evaluation(inference_params(), training_metrics)  # (its own State: the
+                # training env_state is untouched, as in the reference)
             logging.info(metrics)
             progress_fn(current_step, metrics)
             policy_params_fn(current_step, make_policy, inference_params())
