@@ -225,7 +225,8 @@ typedef struct vnl_ppo_head_args {
   int32_t normalize_advantage, pad_;
   float *g_logits, *g_baseline, *g_lat_mean, *g_lat_logvar; /* d total_loss / d (network outputs) */
   float *vs, *advantages;                                   /* [T*B] GAE outputs (advantages before normalisation) */
-  float *metrics; /* [8]: total_loss, policy_loss, v_loss, entropy_loss, kl_loss_intention, explained_variance, 0, 0 */
+  float *metrics; /* [8]: total_loss, policy_loss, v_loss, entropy_loss, kl_loss_intention, explained_variance,
+                   * advantage mean, advantage std (before normalisation) */
 } vnl_ppo_head_args;
 /* workspace: 4 + 4 * 256 floats of device memory (statistics and per-block partial sums) */
 #define VNL_PPO_HEAD_WORKSPACE_FLOATS (4 + 4 * 256)
@@ -288,7 +289,8 @@ int64_t vnl_ppo_update_num_params(const vnl_ppo_update*);
  * stream): "vs", "advantages" [T*B], "values" [T*B + B] (baseline then bootstrap), "logits" [T*B][2 act],
  * "latent_mean", "latent_logvar" [T*B][latent] */
 int vnl_ppo_update_buffer(const vnl_ppo_update*, const char* name, float** dev_ptr, int64_t* count);
-/* metrics [8] as vnl_ppo_head */
+/* metrics [9]: [0..8) as vnl_ppo_head, [8] prediction_corr -- the mean of corrcoef([vs ; reward * reward_scaling]) over
+ * its (2T)^2 entries (reference intention_losses.py:186-188); 0 when 2T * B floats exceed 60 KB of LDS */
 int vnl_ppo_minibatch_grad(vnl_ppo_update*, const float* params, const vnl_ppo_batch*, const vnl_ppo_hparams*, float* grads,
                            float* metrics, void* stream);
 

@@ -190,7 +190,7 @@ def drifted(rep: np.ndarray) -> np.ndarray:
             ((r[..., 3] > 0) & (r[..., 4] > KINK_MARGIN_MAX)) | (r[..., 7] > ROW_DEPTH_MAX)).any(axis=-1)
 
 
-def check_control_step(err: dict, dev: dict, rep: np.ndarray, verbose: bool = True) -> int:
+def check_control_step(err: dict, dev: dict, rep: np.ndarray, verbose: bool = True, max_flipped: int | None = None) -> int:
     """Assertion of a multi-substep follow comparison.  Every env within max(TOL, K_SENS x its float32 sensitivity);
     an env outside that bound must SHOW a flipped decision in its report (`drifted`) and stay within 1000 x its
     sensitivity; at most 1 % (at least 2) of the envs may be in that state.  Returns the number of such envs.
@@ -204,7 +204,8 @@ def check_control_step(err: dict, dev: dict, rep: np.ndarray, verbose: bool = Tr
         assert_no_less_accurate_than_f32_oracle(err, dev)
     if verbose:
         print(f"   envs whose later decisions flipped against the oracle's drifted state: {int(flipped.sum())} of {B}")
-    assert flipped.sum() <= max(2, B // 100), int(flipped.sum())
+    # (1 % for the rodent; a model whose contacts sit at their activation threshold passes its own allowance)
+    assert flipped.sum() <= (max(2, B // 100) if max_flipped is None else max_flipped), int(flipped.sum())
     for f, idx in viol.items():
         unexplained = [int(i) for i in idx if not flipped[i]]
         assert not unexplained, (f, unexplained[:8], err[f][unexplained[:8]], dev[f][unexplained[:8]])

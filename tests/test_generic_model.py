@@ -90,19 +90,17 @@ def test_ant_model_on_gpu_matches_oracle():
     ps = st.pipeline_state
     for k, tol in (("qpos", 1e-6), ("xpos", 2e-6)):
         assert H.scaled_err(getattr(ps, k).reshape(B, -1).cpu().numpy(), ost[k]) < tol, k
-    # qacc passes through the 6-iteration constraint solve: an env at a contact-activation threshold is sensitive
-    # to float32 rounding (the float32 host build shows the same), so per-env quantiles rather than the maximum
-    qa = ps.qacc_warmstart.cpu().numpy()
-    per_env_a = np.array([H.scaled_err(qa[i], ost["qacc_warmstart"][i]) for i in range(B)])
-    assert np.median(per_env_a) < 2e-6 and np.quantile(per_env_a, 0.9) < 2e-5, (np.median(per_env_a), per_env_a.max())
     assert H.scaled_err(st.obs.cpu().numpy(), ost["obs"]) < 1e-6
-    for _ in range(2):
-        act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1).astype(np.float32)
-        st = env.step(st, torch.from_numpy(act))
-        o.env_step(ost, act)
-    per_env = np.array([H.scaled_err(ps.qvel[i].cpu().numpy(), ost["qvel"][i]) for i in range(B)])
-    assert np.median(per_env) < 1e-4 and np.quantile(per_env, 0.9) < 1e-2, (np.median(per_env), per_env.max())
-    # (one env in 128 sits on a contact switch: the float32 host build deviates there by the same 1e-2)
-    per_env_q = np.array([H.scaled_err(ps.qpos[i].cpu().numpy(), ost["qpos"][i]) for i in range(B)])
-    assert np.median(per_env_q) < 1e-5 and np.quantile(per_env_q, 0.9) < 1e-3, (np.median(per_env_q), per_env_q.max())
+    # one control step against the oracles made to follow the product's solver decisions (tests/parity.py): every env
+    # within max(1e-5 of the array's scale, 50 x the float32 oracle's own deviation on that env) -- no quantiles
+    import parity as P
+
+    act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1).astype(np.float32)
+    o32 = H.make_oracle(env, "f32")
+    st, err, dev, rep, ost = P.control_step_follow(env, o, o32, sf, noise, act)
+    print("\n[ant control step, 128 envs] " + ", ".join(f"{k}: max {v.max():.2e} median {np.median(v):.2e}" for k, v in err.items()))
+    # the ant's four sphere feet rest AT their contact margin in the synthetic clip, so a contact row's presence is a
+    # float32 tie far more often than for the rodent (9 of 128 envs measured on the device, 1 of 32 in the host build):
+    # those envs must still show the flipped decision and stay within 1000 x their sensitivity (check_control_step)
+    P.check_control_step(err, dev, rep, max_flipped=B // 8)
     assert np.array_equal(st.done.cpu().numpy(), ost["done"].astype(np.float32))

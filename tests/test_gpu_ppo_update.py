@@ -72,6 +72,8 @@ def test_hip_update_matches_autograd_and_numpy(cfg):
     for i, k in enumerate(("total_loss", "policy_loss", "v_loss", "entropy_loss", "kl_loss_intention", "explained_variance")):
         ref = float(m_ref[k])
         assert abs(mt[i] - ref) <= 2e-5 * max(abs(ref), abs(float(m_ref["total_loss"]))), (k, mt[i], ref)
+    # metrics[8]: mean of corrcoef([vs ; reward * scaling]) (intention_losses.py:186-188), float64 autograd path as reference
+    assert abs(mt[8] - float(m_ref["prediction_corr"])) < 2e-5, (mt[8], float(m_ref["prediction_corr"]))
     # gradients per tensor, relative to that tensor's largest gradient entry
     worst = 0.0
     for lay, off0 in ((nets.policy_network.layout, 0), (nets.value_network.layout, n_pol)):

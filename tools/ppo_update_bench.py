@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--torch", action="store_true", help="time the autograd path instead (hipBLASLt)")
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile of the hand-written path (64 / 128)")
+    ap.add_argument("--wg-target", type=int, default=0, help="workgroups a split-K weight gradient is split up to (default 256)")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses, running_statistics
     from vnl_brax_imitation_amd.ppo_imitation.intention_policy_network import LeafParams
@@ -46,8 +47,8 @@ def main():
             lp.policy.gather_grads(), lp.value.gather_grads()
     else:
         upd = hip_update.HipPPOUpdate(nets, cfg["T"], cfg["B"], dev, **HP)
-        if a.tile:
-            assert upd.lib.vnl_ppo_update_tune(upd.h, a.tile) == 0
+        if a.tile or a.wg_target:
+            assert upd.lib.vnl_ppo_update_tune(upd.h, a.tile, a.wg_target) == 0
 
         def step():
             upd.grad(flat, ndev, data, noise, grads)
@@ -74,7 +75,7 @@ def main():
     macs_p = 795 * 256 + 256 * 128 + 2 * 128 * 64 + 296 * 128 + 128 * 256 + 256 * 60
     macs_v = 232 * 1024 + 1024 * 1024 + 1024
     flop = 2.0 * 3.0 * (N * macs_p + N * macs_v) + 2.0 * cfg["B"] * macs_v  # fwd + dX + dW (+ the bootstrap rows' forward)
-    print(json.dumps({"backend": "torch" if a.torch else "hip", "tile": a.tile, "ms_per_minibatch_step": ms, "tflops": flop / ms / 1e9,
+    print(json.dumps({"backend": "torch" if a.torch else "hip", "tile": a.tile, "wg_target": a.wg_target, "ms_per_minibatch_step": ms, "tflops": flop / ms / 1e9,
                       "gflop_per_step": flop / 1e9, "samples": N}))
 
 

@@ -958,6 +958,7 @@ __global__ void vnl_ppo_finish_kernel(vnl_ppo_head_args a, const float* stats, i
   a.metrics[5] = 1.f - vl / stats[2], a.metrics[6] = stats[0], a.metrics[7] = stats[1];
 }
 
+int vnl_ppo_head_phase_(const vnl_ppo_head_args* a, float* workspace, void* stream, int phase);
 extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* stream) {
   if (!a || !workspace || a->T <= 0 || a->B <= 0 || a->act <= 0 || a->latent <= 0)
     return fail(VNL_ERR_ARG, "vnl_ppo_head: bad sizes");
@@ -966,12 +967,20 @@ extern "C" int vnl_ppo_head(const vnl_ppo_head_args* a, float* workspace, void* 
                         a->g_baseline, a->g_lat_mean, a->g_lat_logvar, a->vs, a->advantages, a->metrics};
   for (const void* p : need)
     if (!p) return fail(VNL_ERR_ARG, "vnl_ppo_head: null buffer");
+  return vnl_ppo_head_phase_(a, workspace, stream, 3);
+}
+
+// phase bit 1: GAE + statistics (needs the value outputs only); bit 2: per-sample head + the metrics.  vnl_ppo.hip runs
+// phase 1 on the value stream while the intention network's forward is still in flight on the other one.
+int vnl_ppo_head_phase_(const vnl_ppo_head_args* a, float* workspace, void* stream, int phase) {
   const int groups_per_block = VNL_HEAD_THREADS / VNL_HEAD_GROUP, N = a->T * a->B;
   int nblk = (N + groups_per_block - 1) / groups_per_block;
   if (nblk > VNL_HEAD_MAXBLK) nblk = VNL_HEAD_MAXBLK;
-  hipLaunchKernelGGL(vnl_ppo_gae_kernel, dim3(1), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
-  hipLaunchKernelGGL(vnl_ppo_head_kernel, dim3(nblk), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
-  hipLaunchKernelGGL(vnl_ppo_finish_kernel, dim3(1), dim3(VNL_FINISH_THREADS), 0, (hipStream_t)stream, *a, (const float*)workspace, nblk);
+  if (phase & 1) hipLaunchKernelGGL(vnl_ppo_gae_kernel, dim3(1), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
+  if (phase & 2) {
+    hipLaunchKernelGGL(vnl_ppo_head_kernel, dim3(nblk), dim3(VNL_HEAD_THREADS), 0, (hipStream_t)stream, *a, workspace);
+    hipLaunchKernelGGL(vnl_ppo_finish_kernel, dim3(1), dim3(VNL_FINISH_THREADS), 0, (hipStream_t)stream, *a, (const float*)workspace, nblk);
+  }
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

@@ -21,6 +21,7 @@
 #include "../../include/vnl.h"
 
 void vnl_set_error_(const char* msg);
+int vnl_ppo_head_phase_(const vnl_ppo_head_args* a, float* workspace, void* stream, int phase);  // vnl_lib.hip
 static int pfail(int code, const char* msg) {
   vnl_set_error_(msg);
   return code;
@@ -317,6 +318,7 @@ struct SlabPool {  // host-side bump allocator over the slab buffer + the list o
   size_t cap, used;
   ReduceJobs jobs;
   int tile;  // 0: by shape, 64 / 128: forced (tuning knob of tools/ppo_update_bench.py)
+  int wg_target = 256;
 };
 
 static void launch_wgrad_group(hipStream_t st, GemmGroup& grp) {
@@ -355,7 +357,7 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
     const bool big = pool->tile ? pool->tile == 128 : (in >= 512 && out >= 512);  // the one big weight gradient: 128 x 128 x 4 slabs
     const long tiles = big ? t128 : t64;
     int splits = 1;
-    while (splits * 2 <= max_splits && tiles * splits < 256) splits *= 2;
+    while (splits * 2 <= max_splits && tiles * splits < pool->wg_target) splits *= 2;
     const size_t tot = ((size_t)M * N + 3) & ~(size_t)3;
     if (splits > 1 && (pool->used + splits * tot > pool->cap || pool->jobs.njobs >= VNL_MAX_JOBS)) splits = 1;
     if (splits > 1) {
@@ -556,6 +558,54 @@ __global__ void __launch_bounds__(256) latent_bwd_kernel(const float* dD0, int l
 }
 
 // the two heads' outputs side by side [N][2 lat] -> contiguous mean / logvar arrays for the loss head
+// metrics["prediction_corr"] (intention_losses.py:186-188): the mean of jnp.corrcoef over the 2T rows [vs ; reward *
+// scaling], each a variable with B observations.  One workgroup: centred rows in LDS, then the (2T)^2 normalised dot
+// products, clamped to [-1, 1] as jnp.corrcoef does; a constant row gives NaN, as there.
+__global__ void __launch_bounds__(256) prediction_corr_kernel(const float* vs, const float* reward, float scale, int T, int B,
+                                                              float* out) {
+  extern __shared__ float xs[];  // [2T][B] centred, then [2T] norms
+  __shared__ float red[256];
+  const int R = 2 * T, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float* nrm = xs + (size_t)R * B;
+  for (int r = w; r < R; r += 4) {
+    const float* src = r < T ? vs + (size_t)r * B : reward + (size_t)(r - T) * B;
+    const float k = r < T ? 1.f : scale;
+    float s1 = 0.f;
+    for (int c = lane; c < B; c += 64) s1 += src[c] * k;
+    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+    const float mu = s1 / (float)B;
+    float q = 0.f;
+    for (int c = lane; c < B; c += 64) {
+      const float d = src[c] * k - mu;
+      xs[(size_t)r * B + c] = d;
+      q += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) nrm[r] = sqrtf(q);
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int pq = tid; pq < R * R; pq += 256) {
+    const int i = pq / R, j = pq - i * R;
+    // (every lane starts at a column of its own: rows are B floats apart, so equal columns would share one LDS bank)
+    float d = 0.f;
+    int col = tid % B;
+    for (int k = 0; k < B; k++) {
+      d += xs[(size_t)i * B + col] * xs[(size_t)j * B + col];
+      col = col + 1 == B ? 0 : col + 1;
+    }
+    const float c = d / (nrm[i] * nrm[j]);
+    acc += c != c ? c : fminf(fmaxf(c, -1.f), 1.f);
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) red[tid] += red[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) *out = red[0] / (float)(R * R);
+}
+
 __global__ void __launch_bounds__(256) split_ml_kernel(const float* ml, float* mean, float* logvar, int N, int lat) {
   const size_t n = (size_t)N * lat;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -587,8 +637,8 @@ struct vnl_ppo_update {
   size_t dz_floats = 0;
   hipStream_t s2 = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int tile = 0;
-  size_t slab_floats = 0, part_floats = 0;
+  int tile = 0, wg_target = 512;  // (wg_target: workgroups a split-K weight gradient is split up to; 512 measured best)
+  size_t slab_floats = 0, slab_floats_p = 0, part_floats = 0;  // (slab_floats_p: the intention network's share, at the end)
   std::vector<float*> encH, encY, encS, decH, decY, decS, valZ, valA;
 };
 
@@ -610,9 +660,10 @@ extern "C" void vnl_ppo_update_destroy(vnl_ppo_update* u) {
 }
 
 // tuning knob of tools/ppo_update_bench.py (not part of include/vnl.h): force the GEMM tile (64 / 128; 0 = by shape)
-extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile) {
+extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
   if (!u || (tile != 0 && tile != 64 && tile != 128)) return pfail(VNL_ERR_ARG, "vnl_ppo_update_tune: tile must be 0, 64 or 128");
   u->tile = tile;
+  if (wg_target > 0) u->wg_target = wg_target;
   return VNL_OK;
 }
 
@@ -731,7 +782,10 @@ extern "C" int vnl_ppo_update_create(const vnl_ppo_net_spec* sp, int32_t T, int3
     AL(a, Nv * u->val[i].out);
     u->valZ.push_back(z), u->valA.push_back(a);
   }
-  u->slab_floats = 8 * u->n_total + 4096;  // split-K slabs of every weight gradient of a step (wgrad falls back to one slab)
+  // split-K slabs of every weight gradient of a step (wgrad falls back to one slab) + the LayerNorm backward's per-block
+  // partial sums (80 blocks x 2 h each)
+  u->slab_floats_p = 8 * u->n_policy + 4096 + (size_t)80 * 2 * wmax * (u->enc.size() + u->dec.size());
+  u->slab_floats = 8 * (u->n_total - u->n_policy) + 4096 + u->slab_floats_p;
   AL(u->slabs, u->slab_floats);
   if (rc == VNL_OK && hipStreamCreateWithFlags(&u->s2, hipStreamNonBlocking) != hipSuccess) rc = pfail(VNL_ERR_HIP, "hipStreamCreate");
   for (int k = 0; k < 4 && rc == VNL_OK; k++)
@@ -791,11 +845,23 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   hipStream_t st = (hipStream_t)stream, sp2 = u->s2;
   const vnl_ppo_net_spec& sp = u->spec;
   const int N = u->N, Nv = u->Nv, no = sp.obs_size, lat = sp.latent_size, A2 = 2 * sp.action_size;
-  SlabPool pool{u->slabs, u->slab_floats, 0, {}, u->tile};
+  // split-K slabs and the deferred reductions, one pool per chain: the intention network's are summed on its own stream
+  // as soon as its grouped weight-gradient launch is done, beside the value MLP's last GEMMs
+  SlabPool pool{u->slabs, u->slab_floats - u->slab_floats_p, 0, {}, u->tile};
+  SlabPool poolP{u->slabs + (u->slab_floats - u->slab_floats_p), u->slab_floats_p, 0, {}, u->tile};
   pool.jobs.njobs = 0, pool.jobs.start4[0] = 0;
+  poolP.jobs.njobs = 0, poolP.jobs.start4[0] = 0;
+  pool.wg_target = poolP.wg_target = u->wg_target;
   GemmGroup group;
   group.n = 0;
-  Gemm GV{st, &pool}, GP{sp2, &pool, &group};
+  Gemm GV{st, &pool}, GP{sp2, &poolP, &group};
+  auto reduce_pool = [](SlabPool& pl, hipStream_t s) {
+    if (pl.jobs.njobs == 0) return;
+    const unsigned total4 = pl.jobs.start4[pl.jobs.njobs];
+    unsigned blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks), dim3(256), 0, s, pl.jobs);
+  };
   size_t dz_used = 0;
   auto dz_alloc = [&](size_t n) {  // (sized in create for every layer's N x out: cannot run out)
     float* q = u->dzarena + dz_used;
@@ -860,7 +926,6 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     }
   }
   PCHK(hipEventRecord(u->ev[1], sp2));
-  PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
   // ---------------- loss head: GAE, clipped surrogate, value / entropy / KL terms and d loss / d (network outputs)
   {
     vnl_ppo_head_args a{};
@@ -873,7 +938,18 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     a.min_std = hp->min_std, a.var_scale = hp->var_scale, a.normalize_advantage = hp->normalize_advantage;
     a.g_logits = u->gl, a.g_baseline = u->gb, a.g_lat_mean = u->gklm, a.g_lat_logvar = u->gkll;
     a.vs = u->vs, a.advantages = u->adv, a.metrics = metrics;
-    int rc = vnl_ppo_head(&a, u->headws, stream);
+    // GAE needs the value outputs only: it runs while the intention network's forward is still in flight
+    int rc = vnl_ppo_head_phase_(&a, u->headws, stream, 1);
+    if (rc != VNL_OK) return rc;
+    // metrics[8] = prediction_corr (a metric only), in the same slack; 0 when the 2T rows do not fit in LDS
+    const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
+    if (lds <= 60 * 1024)
+      hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(256), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
+                         u->T, u->B, metrics + 8);
+    else
+      PCHK(hipMemsetAsync(metrics + 8, 0, sizeof(float), st));
+    PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
+    rc = vnl_ppo_head_phase_(&a, u->headws, stream, 2);
     if (rc != VNL_OK) return rc;
   }
   PCHK(hipEventRecord(u->ev[2], st));
@@ -918,7 +994,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
       if (i > 0) {
         const DenseP& pd = u->dec[i - 1];
         float* dnext = dz_alloc((size_t)N * pd.out);
-        ln_bwd(u, &pool, sp2, dcur, u->decH[i - 1], u->decS[i - 1], P + pd.g, dnext, Gr + pd.g, N, pd.out);
+        ln_bwd(u, &poolP, sp2, dcur, u->decH[i - 1], u->decS[i - 1], P + pd.g, dnext, Gr + pd.g, N, pd.out);
         dz = dnext, dzw = pd.out;
       }
     }
@@ -935,22 +1011,18 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     for (int i = (int)u->enc.size() - 1; i >= 0; i--) {
       const DenseP& d = u->enc[i];
       float* dzi = dz_alloc((size_t)N * d.out);
-      ln_bwd(u, &pool, sp2, dy, u->encH[i], u->encS[i], P + d.g, dzi, Gr + d.g, N, d.out);
+      ln_bwd(u, &poolP, sp2, dy, u->encH[i], u->encS[i], P + d.g, dzi, Gr + d.g, N, d.out);
       const float* xin = i > 0 ? u->encY[i - 1] : u->trajp;
       const int ldx = i > 0 ? u->enc[i - 1].out : u->ntp;
       GP.wgrad(xin, ldx, dzi, d.out, Gr + d.w, Gr + d.b, d.in, d.out, N);
       if (i > 0) GP.run(false, true, EPI_NONE, dzi, d.out, P + d.w, d.out, dy, d.in, N, d.in, d.out);
     }
     GP.flush();  // every weight gradient of the intention network: one grouped launch
+    reduce_pool(poolP, sp2);
   }
   PCHK(hipEventRecord(u->ev[3], sp2));
   PCHK(hipStreamWaitEvent(st, u->ev[3], 0));
-  if (pool.jobs.njobs > 0) {  // every split-K weight / bias gradient of the step, summed in a fixed order by one launch
-    const unsigned total4 = pool.jobs.start4[pool.jobs.njobs];
-    unsigned blocks = (total4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks), dim3(256), 0, st, pool.jobs);
-  }
+  reduce_pool(pool, st);  // the value MLP's split-K weight / bias gradients, summed in a fixed order by one launch
   hipError_t e = hipGetLastError();
   if (prev != u->device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return pfail(VNL_ERR_HIP, hipGetErrorString(e));

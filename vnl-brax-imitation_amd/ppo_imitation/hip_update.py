@@ -51,7 +51,7 @@ class HipPPOUpdate:
         hp.clipping_epsilon, hp.kl_weight, hp.min_std, hp.var_scale = clipping_epsilon, kl_weight, dist._min_std, dist._var_scale
         hp.normalize_advantage = int(normalize_advantage)
         self.hp = hp
-        self.metrics = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.metrics = torch.zeros(9, dtype=torch.float32, device=dev)
 
     def __del__(self):
         try:
@@ -76,7 +76,8 @@ class HipPPOUpdate:
              grads: torch.Tensor) -> torch.Tensor:
         """`data`: TIME-MAJOR Transition [T, B, ...] (next_observation: at least its last row [.., B, obs]); `noise`:
         {"latent": [T,B,latent], "entropy": [T,B,act]} N(0,1) draws.  Writes d loss / d params into `grads` (flat, same
-        layout) and returns the metrics tensor [8] (total, policy, value, entropy, KL losses, explained variance, ...)."""
+        layout) and returns the metrics tensor [9] (total, policy, value, entropy, KL losses, explained variance, advantage mean / std,
+        prediction_corr)."""
         T, B = self.T, self.B
         assert params.is_contiguous() and grads.is_contiguous() and params.numel() == grads.numel() == self.num_params
         c = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731

@@ -228,13 +228,9 @@ def train(
                 kl_weight=kl_weight)
         upd = hip_upd[(T, mb)]
         mt = upd.grad(training_state.params, normalizer_params, data_tm, noise, flat_grad)
+        hip_upd["last_metrics"] = mt
         metrics = {k: mt[i] for i, k in enumerate(_METRIC_KEYS)}
-        with torch.no_grad():
-            if T * 2 <= 256:
-                vs = upd.buffer("vs").view(T, mb)
-                metrics["prediction_corr"] = ppo_losses._corrcoef(torch.cat([vs, data_tm.reward * reward_scaling], dim=0)).mean()
-            else:
-                metrics["prediction_corr"] = torch.zeros((), device=device)
+        metrics["prediction_corr"] = mt[8]  # computed by the library beside the backward passes
         return metrics
 
     def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
@@ -322,10 +318,17 @@ def train(
         torch.cuda.current_stream(device).wait_stream(side)
         g["keys"] = sorted(m.keys())
         g["acc"] = torch.zeros(len(g["keys"]), device=device)
+        if use_hip_update:  # the library's metric vector, gathered into key order by one index_add of nine floats
+            slot = {k: i for i, k in enumerate(_METRIC_KEYS)}
+            slot["prediction_corr"] = 8
+            g["slots"] = torch.tensor([slot[k] for k in g["keys"]], dtype=torch.int64, device=device)
         g["graph"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["graph"]):
             m = body()
-            g["acc"] += torch.stack([m[k].to(torch.float32).reshape(()) for k in g["keys"]])
+            if use_hip_update:
+                g["acc"] += hip_upd["last_metrics"][g["slots"]]
+            else:
+                g["acc"] += torch.stack([m[k].to(torch.float32).reshape(()) for k in g["keys"]])
         with torch.no_grad():  # the warm-up iterations must not count as training
             p.copy_(saved[0])
             for k, v in saved[1].items():
