@@ -1,6 +1,7 @@
 """PPO training step on the GPU: the hipGraph-captured minibatch step must reproduce the eager one."""
 import functools
 
+import numpy as np
 import pytest
 import torch
 
@@ -74,3 +75,23 @@ def test_training_with_evaluation_on_gpu():
     assert 0 < metrics["eval/avg_episode_length"] <= 20
     act, extras = make_policy(params, deterministic=True)(torch.zeros(4, 795, device=dev), torch.zeros(4, 232, device=dev), None)
     assert act.shape == (4, 30) and extras == {} and torch.isfinite(act).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the round's GPU box has one)")
+def test_two_rank_rccl_training_step():
+    """train() over RCCL with two ranks, one per GPU (reference train.py:485-487 asserts identical replicas; so does
+    ours at the end of train()): gradient all-reduce between graph replays, normaliser statistics over the global batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(H.ROOT, "tools", "train_bench.py"), "--steps", "1", "--envs-per-gpu", "256",
+           "--updates", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and np.isfinite(r["total_loss"]) and r["env_steps"] == 2 * 256 * 20

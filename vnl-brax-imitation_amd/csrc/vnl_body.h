@@ -7,7 +7,7 @@
 //                              contacts, dofs), followed by VNL_SYNC()
 //     VNL_SERIAL     { ... }   one lane walks the kinematic tree (parent -> child chains)
 //     wave_sum(x)              cross-lane reduction; scalars derived from it are wave-uniform
-// Every array that crosses a region lives in LDS (`s[...]`, ~25 KB per env, 6 envs per CU);
+// Every array that crosses a region lives in LDS (`s[...]`, 20.2 KB per env for the rodent: 8 envs per CU);
 // HBM is touched only to load the carried state and to store the new state / obs / traj, with
 // row-major [env][feature] buffers so those accesses are contiguous per wave.
 //

@@ -590,6 +590,7 @@ __global__ void __launch_bounds__(256) prediction_corr_kernel(const float* vs, c
     // (every lane starts at a column of its own: rows are B floats apart, so equal columns would share one LDS bank)
     float d = 0.f;
     int col = tid % B;
+#pragma unroll 8  // eight independent LDS read pairs in flight (one per trip was 35 us for T = 20, B = 128)
     for (int k = 0; k < B; k++) {
       d += xs[(size_t)i * B + col] * xs[(size_t)j * B + col];
       col = col + 1 == B ? 0 : col + 1;
