@@ -92,11 +92,20 @@ typedef struct vnl_envspec {
   int32_t flags;
   float done_threshold;          /* done when the UNSCALED rtrunk is below it: 0 (rodent.py:213), 0.5 (humanoid.py:199) */
   const float* center_of_mass;   /* (C,T,3) reference for rcom (humanoid.py:273), or NULL: body_positions[com_ref_col] (rodent.py:279) */
+  /* with VNL_ENV_WEIGHTS: weights of rcom, rvel, rtrunk, rquat, ract, rapp in the total reward (ant.py:182-188:
+   * 0.05, 0.01, 0.20, 0.01, 0.001, -); without it 0.01, 0.01, 0.01, 0.01, 0.0001, 0.01 (rodent.py:203-209) */
+  float reward_weights[6];
 } vnl_envspec;
 #define VNL_ENV_REWARD_OLD_STATE 1 /* reward terms from the state BEFORE the step (humanoid.py:195: _calculate_reward(state, ..)) */
 #define VNL_ENV_TERM_MEAN 2        /* termination error = means of |.| (humanoid.py:256-260), not the matrix-1 / L1 norms */
 #define VNL_ENV_NO_RAPP 4          /* no appendage reward term */
 #define VNL_ENV_OBS_QPOS_QVEL 8    /* observation = [qpos, qvel] only (humanoid.py:354-368) */
+/* AntTracking (envs/ant.py:172-291) = the four above | the four below, done_threshold 0 */
+#define VNL_ENV_WEIGHTS 16         /* reward_weights[] replace the built-in weights */
+#define VNL_ENV_RACT_ACTION 32     /* ract = 0.01 * -0.015 * sum(action^2) / nu (ant.py:277), not the actuator forces */
+#define VNL_ENV_METRICS_UNSCALED 64 /* metrics / termination_error hold the UNWEIGHTED terms (ant.py:197,216-225) */
+#define VNL_ENV_TRAJ_OLD_FRAME 128 /* the step's reference slice starts at the OLD cur_frame + 1: ant.py:178 builds the
+                                    * observation from the un-incremented info */
 
 /* Caller-owned device buffers, row-major [num_envs][count]. */
 typedef struct vnl_state {

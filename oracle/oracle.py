@@ -45,6 +45,7 @@ class EnvSpec(C.Structure):
         ("body_error_multiplier", C.c_double),
         ("flags", C.c_int),
         ("done_threshold", C.c_double),
+        ("reward_weights", C.c_double * 6),
     ]
 
 
@@ -71,6 +72,8 @@ def make_envspec(spec: dict) -> EnvSpec:
     for k in ("healthy_z_lo", "healthy_z_hi", "termination_threshold", "body_error_multiplier"):
         setattr(e, k, float(spec[k]))
     e.flags, e.done_threshold = int(spec.get("flags", 0)), float(spec.get("done_threshold", 0.0))
+    for i, w in enumerate(spec.get("reward_weights") or ()):
+        e.reward_weights[i] = float(w)
     for k in ("body_idxs", "end_eff_idx", "app_body", "app_ref_col", "joint_cols"):
         arr = getattr(e, k)
         for i, v in enumerate(spec[k]):
@@ -109,7 +112,7 @@ class Oracle:
         L.orc_env_step_follow.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p,
                                           C.POINTER(_State), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_glue.argtypes = [C.c_void_p, C.POINTER(EnvSpec), C.POINTER(_Clip), C.c_int, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_State)]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_State)]
         L.orc_set_option.argtypes = [C.c_char_p, C.c_int]
         L.orc_get_option.argtypes = [C.c_char_p]
         L.orc_solver_trace.restype = C.POINTER(C.c_int)
@@ -239,7 +242,7 @@ class Oracle:
         return st, tr, rep
 
     def env_glue(self, st: dict, old_qpos: np.ndarray, old_xpos: np.ndarray, old_qvel=None, old_com1=None,
-                 old_qfrc=None) -> dict:
+                 old_qfrc=None, action=None) -> dict:
         """rodent.py:183-239 on a caller-supplied NEW pipeline state: `st` holds the new qpos / qvel / act /
         qacc_warmstart / xpos / xmat1 / com1 / qfrc_actuator and the OLD frame counters; fills obs / traj / reward /
         done / metrics / termination_error in place and advances the counters."""
@@ -247,7 +250,7 @@ class Oracle:
         oq = np.ascontiguousarray(old_qpos, dtype=self.real)
         ox = np.ascontiguousarray(old_xpos, dtype=self.real).reshape(B, -1)
         cs = self._cstate(st)
-        extra = [None if x is None else np.ascontiguousarray(x, dtype=self.real) for x in (old_qvel, old_com1, old_qfrc)]
+        extra = [None if x is None else np.ascontiguousarray(x, dtype=self.real) for x in (old_qvel, old_com1, old_qfrc, action)]
         rc = self.lib.orc_env_glue(self.model, C.byref(self.spec), C.byref(self._clip), B, oq.ctypes.data, ox.ctypes.data,
                                    *[None if x is None else x.ctypes.data for x in extra], C.byref(cs))
         assert rc == 0

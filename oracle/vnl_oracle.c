@@ -1316,11 +1316,16 @@ typedef struct orc_envspec {
   double healthy_z_lo, healthy_z_hi, termination_threshold, body_error_multiplier;
   int flags;             /* ENV_* below: RodentTracking (0) or HumanoidTracking-style glue */
   double done_threshold; /* done when the UNSCALED rtrunk is below it (rodent.py:213: 0; humanoid.py:199: 0.5) */
+  double reward_weights[6]; /* with ENV_WEIGHTS: rcom, rvel, rtrunk, rquat, ract, rapp (ant.py:182-188) */
 } orc_envspec;
 #define ENV_REWARD_OLD_STATE 1 /* humanoid.py:195: _calculate_reward(state, action) uses the state BEFORE the step */
 #define ENV_TERM_MEAN 2        /* humanoid.py:256-260: means of |.| instead of the matrix-1 / L1 norms */
 #define ENV_NO_RAPP 4
 #define ENV_OBS_QPOS_QVEL 8    /* humanoid.py:354-368 */
+#define ENV_WEIGHTS 16         /* ant.py:182-188: total = 0.05 rcom + 0.01 rvel + 0.20 rtrunk + 0.01 rquat + 0.001 ract */
+#define ENV_RACT_ACTION 32     /* ant.py:277: ract = 0.01 * -0.015 * sum(action^2) / len(action) */
+#define ENV_METRICS_UNSCALED 64 /* ant.py:197,216-225: metrics / termination_error hold the unweighted terms */
+#define ENV_TRAJ_OLD_FRAME 128 /* ant.py:178: _get_obs(data, action, state.info) -- the un-incremented cur_frame */
 
 typedef struct orc_clip {
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
@@ -1486,11 +1491,12 @@ typedef struct {
 
 static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, const orc_data *d, const real *old_qpos,
                      const real *old_xpos, const reward_state *old /* state before the step, for ENV_REWARD_OLD_STATE */,
-                     real *obs, real *traj, orc_state *s, int i) {
+                     const real *action /* this env's action, for ENV_RACT_ACTION (else unused) */, real *obs, real *traj,
+                     orc_state *s, int i) {
   int nj = m->nq - 7, no = obs_size(m, e), nt = traj_size(e);
   int old_frame = s->cur_frame[i], new_frame = old_frame + 1, new_sub = s->sub_clip_frame[i] + 1;
   env_obs(m, e, d, obs);
-  env_traj(m, e, c, d, new_frame, traj);
+  env_traj(m, e, c, d, (e->flags & ENV_TRAJ_OLD_FRAME) ? old_frame : new_frame, traj);
   /* _calculate_reward: rodent.py:195 passes the NEW data (quirk C.1: against the clip row at the OLD cur_frame);
    * humanoid.py:195 passes `state`, i.e. every term comes from the state BEFORE the step */
   reward_state cur = {d->qpos, d->qvel, d->subtree_com + 3, d->qfrc_actuator, d->xpos};
@@ -1523,8 +1529,14 @@ static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c
   if (dist > 1) dist = 1;
   real rquat = REXP(-2 * RFABS((real)0.5 * RACOS(dist)));
   acc = 0;
-  for (int k = 0; k < m->nv; k++) acc += r->qfrc_actuator[k] * r->qfrc_actuator[k];
-  real ract = (real)-0.015 * (acc / m->nv);
+  real ract;
+  if (e->flags & ENV_RACT_ACTION) {
+    for (int k = 0; k < m->nu; k++) acc += action[k] * action[k];
+    ract = (real)0.01 * (real)-0.015 * acc / m->nu;
+  } else {
+    for (int k = 0; k < m->nv; k++) acc += r->qfrc_actuator[k] * r->qfrc_actuator[k];
+    ract = (real)-0.015 * (acc / m->nv);
+  }
   real rapp = 0;
   if (!(e->flags & ENV_NO_RAPP)) {
     acc = 0;
@@ -1539,9 +1551,13 @@ static void env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c
   if (r->qpos[2] < (real)e->healthy_z_lo) healthy = 0;
   if (r->qpos[2] > (real)e->healthy_z_hi) healthy = 0;
   real done = rtrunk < (real)e->done_threshold ? 1 : 0; /* on the unscaled value */
-  rcom *= (real)0.01, rvel *= (real)0.01, rapp *= (real)0.01, rtrunk *= (real)0.01, rquat *= (real)0.01;
-  ract *= (real)0.0001;
-  real total = rcom + rvel + rtrunk + rquat + ract + rapp;
+  static const double builtin_w[6] = {0.01, 0.01, 0.01, 0.01, 0.0001, 0.01}; /* rodent.py:203-209 */
+  const double *w = (e->flags & ENV_WEIGHTS) ? e->reward_weights : builtin_w;
+  real wcom = rcom * (real)w[0], wvel = rvel * (real)w[1], wtrunk = rtrunk * (real)w[2], wquat = rquat * (real)w[3];
+  real wact = ract * (real)w[4], wapp = rapp * (real)w[5];
+  real total = wcom + wvel + wtrunk + wquat + wact + wapp;
+  if (!(e->flags & ENV_METRICS_UNSCALED)) /* rodent.py:228-236 logs the weighted terms, ant.py:216-225 the raw ones */
+    rcom = wcom, rvel = wvel, rtrunk = wtrunk, rquat = wquat, ract = wact, rapp = wapp;
   if (1 - healthy > done) done = 1 - healthy;
   real sub_ok = new_sub < e->sub_clip_length ? 1 : 0;
   if (1 - sub_ok > done) done = 1 - sub_ok;
@@ -1588,7 +1604,7 @@ int orc_env_step_follow(const orc_model *m, const orc_envspec *e, const orc_clip
           memcpy(report + ((size_t)i * e->n_frames + f) * ORC_FOLLOW_REPORT, d->follow_report, sizeof(d->follow_report));
       }
       store_state(m, d, s, i);
-      env_glue(m, e, c, d, old_qpos, old_xpos, &old, obs, traj, s, i);
+      env_glue(m, e, c, d, old_qpos, old_xpos, &old, action + (size_t)i * m->nu, obs, traj, s, i);
     }
     orc_data_destroy(d);
     free(obs), free(traj), free(old_qpos), free(old_xpos), free(old_qvel), free(old_qfrc);
@@ -1609,7 +1625,8 @@ int orc_env_step(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
  * termination_error and advances the counters, exactly as orc_env_step does after its substeps. */
 int orc_env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, int B, const real *old_qpos,
                  const real *old_xpos, const real *old_qvel, const real *old_com1, const real *old_qfrc /* ENV_REWARD_OLD_STATE
-                 only: [B][nv], [B][3], [B][nv] before the step, else NULL */, orc_state *s) {
+                 only: [B][nv], [B][3], [B][nv] before the step, else NULL */, const real *action /* [B][nu], ENV_RACT_ACTION
+                 only, else NULL */, orc_state *s) {
   int no = obs_size(m, e), nt = traj_size(e), nb3 = 3 * m->nbody;
   real *obs = ralloc(no), *traj = ralloc(nt);
   orc_data *d = orc_data_create(m);
@@ -1623,7 +1640,9 @@ int orc_env_glue(const orc_model *m, const orc_envspec *e, const orc_clip *c, in
                         old_com1 ? old_com1 + (size_t)i * 3 : NULL, old_qfrc ? old_qfrc + (size_t)i * m->nv : NULL,
                         old_xpos + (size_t)i * nb3};
     if ((e->flags & ENV_REWARD_OLD_STATE) && !(old_qvel && old_com1 && old_qfrc)) return -1;
-    env_glue(m, e, c, d, old_qpos + (size_t)i * m->nq, old_xpos + (size_t)i * nb3, &old, obs, traj, s, i);
+    if ((e->flags & ENV_RACT_ACTION) && !action) return -1;
+    env_glue(m, e, c, d, old_qpos + (size_t)i * m->nq, old_xpos + (size_t)i * nb3, &old,
+             action ? action + (size_t)i * m->nu : NULL, obs, traj, s, i);
   }
   orc_data_destroy(d);
   free(obs), free(traj);

@@ -311,6 +311,7 @@ def _glue_run(env, oracle, state, old_qpos, old_xpos, old_cur_frame, old_sub_fra
 
 
 def glue_errors(env, o64, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, old_extra=None):
+    # old_extra: (old qvel, old com1, old qfrc_actuator[, action]) for the envs whose reward reads the state before the step
     """obs / traj / the reward terms / done / counters of the product's step against the oracle's glue evaluated on
     the product's OWN post-step pipeline state (so physics sensitivity cannot mask a glue error).  Returns (err, dev32,
     flags): per-env errors vs the float64 oracle scaled by each array's scale, the float32 oracle's own deviation from
@@ -318,14 +319,15 @@ def glue_errors(env, o64, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub
     arithmetic), and the exact-equality flags."""
     a = _glue_run(env, o64, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, old_extra=old_extra)
     b = _glue_run(env, o32, state, old_qpos, old_xpos, old_cur_frame, old_sub_frame, f32=True, old_extra=old_extra)
-    err = {"obs": per_env_scaled(to_np(state.obs), a["obs"]), "traj": per_env_scaled(to_np(state.info["traj"]), a["traj"])}
+    raw = state.info["_raw"]  # the buffers the kernel fills (AntTracking presents obs = [traj | raw obs] and six metrics)
+    err = {"obs": per_env_scaled(to_np(raw["obs"]), a["obs"]), "traj": per_env_scaled(to_np(state.info["traj"]), a["traj"])}
     dev = {"obs": per_env_scaled(b["obs"], a["obs"]), "traj": per_env_scaled(b["traj"], a["traj"])}
 
     def rel(x, ref):
         return np.abs(np.asarray(x, np.float64) - ref) / max(float(np.max(np.abs(ref))), 1e-30)
 
     for j, name in enumerate(METRIC_NAMES):
-        err[name], dev[name] = rel(to_np(state.metrics[name]), a["metrics"][:, j]), rel(b["metrics"][:, j], a["metrics"][:, j])
+        err[name], dev[name] = rel(to_np(raw["metrics"][:, j]), a["metrics"][:, j]), rel(b["metrics"][:, j], a["metrics"][:, j])
     err["reward"], dev["reward"] = rel(to_np(state.reward), a["reward"]), rel(b["reward"], a["reward"])
     err["info.termination_error"] = rel(to_np(state.info["termination_error"]), a["termination_error"])
     dev["info.termination_error"] = rel(b["termination_error"], a["termination_error"])

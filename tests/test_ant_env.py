@@ -1,0 +1,125 @@
+"""AntTracking (reference envs/ant.py:25-438) on the same kernels: SURVEY 8(f) f4.
+
+CPU tier: the float64 host build of the kernels against the dense oracle, and the statements of ant.py that differ from
+the rodent env, checked directly.  GPU tier: one control step through the C-ABI, following the solver decisions, and the
+glue on the product's own state.  The reference's ant clip is not shipped: the clip is a seeded gait around the init pose."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import parity as P
+from vnl_brax_imitation_amd.model import mjcf
+from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
+
+ANT_NPZ = os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "ant.npz")
+PARAMS = dict(solver="cg", iterations=6, ls_iterations=6)
+
+
+def _clip(m, T=60):
+    t = np.arange(T)[:, None] * 0.02
+    q = np.zeros((T, 15))
+    q[:, 2], q[:, 3] = 0.55, 1.0
+    q[:, 0] = 0.2 * t[:, 0]
+    q[:, 7:] = np.array([0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0]) + 0.15 * np.sin(2 * np.pi * 1.5 * t + np.arange(8))
+    return pp.process_qpos(m, q, max_qvel=20.0, dt=0.02)
+
+
+def _env(B, real="float", device="cpu", **kw):
+    from vnl_brax_imitation_amd import envs
+
+    m = mjcf.CompiledModel.load(ANT_NPZ)
+    lib = H.hostsim_library(real) if device == "cpu" else None
+    return envs.get_environment("ant", params=PARAMS, clip_length=60, episode_length=20, reference_clip=_clip(m), model=m,
+                                num_envs=B, device=device, _library=lib,
+                                _dtype=torch.float64 if real == "double" else torch.float32, **kw)
+
+
+def _oracle(env, precision="f64"):
+    from oracle.oracle import Oracle
+    from vnl_brax_imitation_amd.model import blob
+
+    m = env.sys
+    o = Oracle(blob.to_blob(m), precision)
+    o.bind_env(env.env_spec(), env.clip_arrays(0), int(m.scalars["nbody"]), int(m.scalars["nq"]), int(m.scalars["nv"]),
+               int(m.scalars["nu"]))
+    return o
+
+
+def test_ant_env_float64_build_matches_oracle_and_reference_semantics():
+    B = 6
+    env = _env(B, "double")
+    nb = 10  # brax's fused body list: world, torso and the eight bodies that carry a hinge
+    assert env.env_spec()["nb"] == nb and int(env.sys.scalars["eulerdamp"]) == 0
+    ntraj = 5 * (2 * nb * 3 + 3 + 8)
+    assert env.traj_size == ntraj and env.observation_size == ntraj + 15 + 14
+    st = env.reset()
+    assert (st.info["cur_frame"] == 0).all()  # ant.py:103: start_frame = 0
+    o = _oracle(env)
+    ost = o.env_reset(np.zeros(B, np.int32), np.zeros((B, 15)))
+    ps, raw = st.pipeline_state, st.info["_raw"]
+    for k in ("qpos", "qvel", "xpos", "qacc_warmstart"):
+        assert H.scaled_err(getattr(ps, k).reshape(B, -1).numpy(), ost[k]) < 1e-10, k
+    # obs = [traj features | qpos | qvel] (ant.py:322-338)
+    assert torch.equal(st.obs, torch.cat((st.info["traj"], ps.qpos, ps.qvel), 1))
+    assert H.scaled_err(raw["obs"].numpy(), ost["obs"]) < 1e-12 and H.scaled_err(st.info["traj"].numpy(), ost["traj"]) < 1e-11
+    assert sorted(st.metrics) == sorted(("rcom", "rvel", "rtrunk", "rquat", "ract", "termination_error"))
+    rng = np.random.default_rng(0)
+    c = env.clip_arrays(0)
+    for step in range(3):
+        old = {k: getattr(ps, k).clone() for k in ("qpos", "qvel", "subtree_com_root")}
+        old_frame = st.info["cur_frame"].clone()
+        ost = P.oracle_state_from(env, o, st)
+        act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1)
+        st = env.step(st, torch.from_numpy(act))
+        o.env_step(ost, act)
+        assert H.scaled_err(ps.qpos.numpy(), ost["qpos"]) < 1e-9 and H.scaled_err(ps.qvel.numpy(), ost["qvel"]) < 1e-8
+        # (the reward weights and the termination threshold are float32 in the C-ABI: 0.05f != 0.05, 0.9f != 0.9)
+        assert np.abs(raw["metrics"].numpy() - ost["metrics"]).max() < 1e-8 and np.abs(st.reward.numpy() - ost["reward"]).max() < 1e-7
+        assert np.array_equal(st.done.numpy(), ost["done"]) and H.scaled_err(st.info["traj"].numpy(), ost["traj"]) < 1e-8
+        assert torch.equal(st.obs, torch.cat((st.info["traj"], ps.qpos, ps.qvel), 1))
+        # --- the statements of ant.py, directly -------------------------------------------------------------------
+        mt = {k: v.numpy() for k, v in st.metrics.items()}
+        f = old_frame.numpy()
+        # every term from the state BEFORE the step (ant.py:180), unweighted in the metrics (ant.py:216-225)
+        ref = np.concatenate([c["velocity"][f], c["angular_velocity"][f], c["joints_velocity"][f]], 1)
+        assert np.abs(mt["rvel"] - np.exp(-0.1 * np.linalg.norm(old["qvel"].numpy() - ref, axis=1))).max() < 1e-12
+        assert np.abs(mt["rcom"] - np.exp(-100 * np.linalg.norm(old["subtree_com_root"].numpy() - c["center_of_mass"][f], axis=1))).max() < 1e-9
+        # ract from the action (ant.py:277)
+        assert np.abs(mt["ract"] - 0.01 * -0.015 * (act ** 2).sum(1) / 8).max() < 1e-15
+        # total (ant.py:182-188), termination_error = rtrunk unweighted (ant.py:197), done = rtrunk < 0 | unhealthy (:200-201)
+        total = 0.05 * mt["rcom"] + 0.01 * mt["rvel"] + 0.20 * mt["rtrunk"] + 0.01 * mt["rquat"] + 0.001 * mt["ract"]
+        assert np.abs(st.reward.numpy() - total).max() < 1e-7
+        assert np.array_equal(mt["termination_error"], mt["rtrunk"]) and np.array_equal(st.info["termination_error"].numpy(), mt["rtrunk"])
+        z = old["qpos"][:, 2].numpy()
+        assert np.array_equal(st.done.numpy() >= 1, (mt["rtrunk"] < 0) | (z < 0.2) | (z > 1.0))
+        # the trajectory features in the observation start at the OLD frame + 1 (ant.py:178: the un-incremented info)
+        want = c["joints"][np.clip(f[:, None] + 1 + np.arange(5), 0, 59)] - ps.qpos[:, 7:].numpy()[:, None, :]
+        assert np.abs(st.info["traj"].numpy()[:, -40:] - want.reshape(B, -1)).max() < 1e-9
+        assert (st.info["cur_frame"].numpy() == f + 1).all()
+
+
+@pytest.mark.gpu
+def test_ant_env_on_gpu():
+    B = 256
+    env = _env(B, device="cuda:0")
+    rng = np.random.default_rng(3)
+    sf, noise = np.zeros(B, np.int32), np.zeros((B, 15), np.float32)
+    act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1).astype(np.float32)
+    o64, o32 = _oracle(env, "f64"), _oracle(env, "f32")
+    st0 = env.reset()
+    ps = st0.pipeline_state
+    old = [P.to_np(x).astype(np.float64).copy() for x in (ps.qpos, ps.xpos, ps.qvel, ps.subtree_com_root, ps.qfrc_actuator)]
+    st, err, dev, rep, ost = P.control_step_follow(env, o64, o32, sf, noise, act)
+    print("\n[ant env control step, 256 envs] " + ", ".join(f"{k}: max {v.max():.2e} median {np.median(v):.2e}" for k, v in err.items()))
+    P.check_control_step(err, dev, rep, max_flipped=B // 8)  # (feet at their contact margin: tests/test_generic_model.py)
+    # glue on the product's own post-step state
+    gerr, gdev, flags = P.glue_errors(env, o64, o32, st, old[0], old[1], np.zeros(B, np.int32), np.zeros(B, np.int32),
+                                      old_extra=old[2:] + [act.astype(np.float64)])
+    print("[ant env glue] " + ", ".join(f"{k} {v.max():.2e}" for k, v in gerr.items()))
+    assert flags["done_equal"] and flags["frames_equal"]
+    for name, v in gerr.items():
+        assert (v <= np.maximum(1e-5, 10 * gdev[name])).all(), (name, v.max(), gdev[name].max())
+    assert torch.equal(st.obs, torch.cat((st.info["traj"], st.pipeline_state.qpos, st.pipeline_state.qvel), 1))

@@ -45,10 +45,12 @@ class EnvSpec(C.Structure):
         ("flags", C.c_int32),
         ("done_threshold", C.c_float),
         ("center_of_mass", f32p),
+        ("reward_weights", C.c_float * 6),
     ]
 
 
 ENV_REWARD_OLD_STATE, ENV_TERM_MEAN, ENV_NO_RAPP, ENV_OBS_QPOS_QVEL = 1, 2, 4, 8  # include/vnl.h VNL_ENV_*
+ENV_WEIGHTS, ENV_RACT_ACTION, ENV_METRICS_UNSCALED, ENV_TRAJ_OLD_FRAME = 16, 32, 64, 128
 
 
 STATE_FLOAT_FIELDS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "xquat", "subtree_com1", "qfrc_actuator",

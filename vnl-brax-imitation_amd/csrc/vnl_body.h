@@ -2174,7 +2174,7 @@ struct EnvWave {
     vreal rcom, rvel, rquat, ract, rapp, healthy;
   };
   VNL_HD RewardTerms reward_terms(int clip, int frame, const vreal* qpos, const vreal* qvel, const vreal* com, const vreal* qfrc,
-                                  const vreal* xpos) const {
+                                  const vreal* xpos, const vreal* action) const {
     int fo = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
     size_t fb = (size_t)clip * ev.T + fo;
     const float* cb = ev.body_positions + fb * ev.nb * 3;
@@ -2198,8 +2198,13 @@ struct EnvWave {
     vreal dist = fmin(vreal(1.), vreal(2.) * dq * dq - vreal(1.));
     r.rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
     acc = vreal(0.);
-    VNL_FOR(d, m.nv) acc += qfrc[d] * qfrc[d];
-    r.ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
+    if (ev.flags & VNL_ENV_RACT_ACTION) {  // ant.py:277: 0.01 * -0.015 * sum(action^2) / len(action)
+      VNL_FOR(i, m.nu) acc += action[i] * action[i];
+      r.ract = vreal(0.01) * vreal(-0.015) * vnl_wave_sum(acc) / (vreal)m.nu;
+    } else {
+      VNL_FOR(d, m.nv) acc += qfrc[d] * qfrc[d];
+      r.ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
+    }
     r.rapp = vreal(0.);
     if (!(ev.flags & VNL_ENV_NO_RAPP)) {
       acc = vreal(0.);
@@ -2235,7 +2240,7 @@ struct EnvWave {
     if (ev.flags & VNL_ENV_REWARD_OLD_STATE) {  // humanoid.py:195,264-311: every term from the state BEFORE the step
       // (parked in this env's metrics row across the substeps: six values kept in registers over the whole physics would
       // raise the kernel's register allocation past two waves per SIMD)
-      const RewardTerms r0 = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, st.com1 + (size_t)e * 3, gqfrc_act(), gxpos());
+      const RewardTerms r0 = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, st.com1 + (size_t)e * 3, gqfrc_act(), gxpos(), ac);
       VNL_SERIAL {
         vreal* mt = st.metrics + (size_t)e * 7;
         mt[0] = r0.rcom, mt[1] = r0.rvel, mt[2] = r0.rquat, mt[3] = r0.ract, mt[4] = r0.rapp, mt[5] = r0.healthy;
@@ -2251,22 +2256,27 @@ struct EnvWave {
     int new_frame = old_frame + 1, new_sub = old_sub + 1;
     RewardTerms rw;
     if (!(ev.flags & VNL_ENV_REWARD_OLD_STATE)) {  // rodent.py:195: _calculate_reward(state, data) -- the NEW data
-      rw = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, s + L.com, gqfrc_act(), gxpos());
+      rw = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, s + L.com, gqfrc_act(), gxpos(), ac);
     } else {
       const vreal* mt = st.metrics + (size_t)e * 7;
       rw = RewardTerms{mt[0], mt[1], mt[2], mt[3], mt[4], mt[5]};
       VNL_SYNC();  // (every lane has read the parked values before lane 0 rewrites the row below)
     }
-    vreal rcom = rw.rcom * vreal(0.01), rvel = rw.rvel * vreal(0.01), rapp = rw.rapp * vreal(0.01), rquat = rw.rquat * vreal(0.01);
-    vreal ract = rw.ract * vreal(0.0001);
     const vreal done_trunk = rtrunk < ev.done_threshold ? vreal(1.) : vreal(0.);  // on the unscaled value (rodent.py:213: < 0)
-    rtrunk *= vreal(0.01);
-    vreal total = rcom + rvel + rtrunk + rquat + ract + rapp;
+    // weighted terms, then their sum in the reference's order (rodent.py:203-210; ant.py:182-188)
+    const vreal wcom = rw.rcom * ev.w_reward[0], wvel = rw.rvel * ev.w_reward[1], wtrunk = rtrunk * ev.w_reward[2];
+    const vreal wquat = rw.rquat * ev.w_reward[3], wact = rw.ract * ev.w_reward[4], wapp = rw.rapp * ev.w_reward[5];
+    const vreal total = wcom + wvel + wtrunk + wquat + wact + wapp;
+    // the metrics hold the weighted terms (rodent.py:228-236), the ant's the raw ones (ant.py:216-225)
+    const bool raw = ev.flags & VNL_ENV_METRICS_UNSCALED;
+    const vreal rcom = raw ? rw.rcom : wcom, rvel = raw ? rw.rvel : wvel, rquat = raw ? rw.rquat : wquat;
+    const vreal ract = raw ? rw.ract : wact, rapp = raw ? rw.rapp : wapp;
+    if (!raw) rtrunk = wtrunk;
     vreal done = fmax(vreal(1.) - rw.healthy, done_trunk);
     done = fmax(new_sub < ev.sub_clip_length ? vreal(0.) : vreal(1.), done);
     if (store_state()) done = vreal(1.);
     write_obs();
-    write_traj(clip, new_frame);
+    write_traj(clip, (ev.flags & VNL_ENV_TRAJ_OLD_FRAME) ? old_frame : new_frame);
     VNL_SERIAL {
       st.reward[e] = nan0(total), st.done[e] = done;
       vreal* mt = st.metrics + (size_t)e * 7;

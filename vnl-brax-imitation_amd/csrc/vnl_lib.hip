@@ -551,6 +551,10 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   e.healthy_lo = es->healthy_z_lo, e.healthy_hi = es->healthy_z_hi;
   e.inv_term_threshold = vreal(1) / es->termination_threshold, e.body_err_mult = es->body_error_multiplier;
   e.flags = es->flags, e.done_threshold = es->done_threshold, e.center_of_mass = nullptr;
+  {
+    const double builtin[6] = {0.01, 0.01, 0.01, 0.01, 0.0001, 0.01};  // rodent.py:203-209
+    for (int k = 0; k < 6; k++) e.w_reward[k] = (es->flags & VNL_ENV_WEIGHTS) ? (vreal)es->reward_weights[k] : (vreal)builtin[k];
+  }
   e.obs_size = (e.flags & VNL_ENV_OBS_QPOS_QVEL) ? d.nq + d.nv : d.nq + 2 * d.nv + 3 * e.nee;
   e.traj_size = e.ref_len * (3 * e.napp + 6 * e.nb + 3 + e.njc);
   bool ok = e.T >= e.ref_len && e.C >= 1 && e.nb >= 1 && e.com_ref_col >= 0 && e.com_ref_col < e.nb && d.nq >= 7 &&

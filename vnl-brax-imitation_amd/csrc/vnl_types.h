@@ -77,6 +77,7 @@ struct DevEnv {
   int obs_size, traj_size;
   int flags; /* VNL_ENV_* of include/vnl.h: which tracking env's glue (rodent / humanoid style) */
   vreal healthy_lo, healthy_hi, inv_term_threshold, body_err_mult, done_threshold;
+  vreal w_reward[6]; /* weights of rcom, rvel, rtrunk, rquat, ract, rapp in the total (built-in or envspec.reward_weights) */
   const int *body_idxs, *end_eff_idx, *app_body, *app_ref_col, *joint_cols;
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
   const float* center_of_mass; /* (C,T,3) or null: reference for rcom (else body_positions[com_ref_col]) */

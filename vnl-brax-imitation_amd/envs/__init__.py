@@ -5,6 +5,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict
 
+from .ant import AntTracking  # noqa: F401
 from .base import Env, PipelineState, State  # noqa: F401
 from .humanoid import HumanoidTracking  # noqa: F401
 from .rodent import RodentMultiClipTracking, RodentTracking  # noqa: F401
@@ -22,4 +23,5 @@ def get_environment(env_name: str, **kwargs) -> Env:
 
 register_environment("rodent", RodentTracking)
 register_environment("rodent_multiclip", RodentMultiClipTracking)
-register_environment("humanoidtracking", HumanoidTracking)  # reference train.py:66
+register_environment("humanoidtracking", HumanoidTracking)  # reference train.py:65
+register_environment("ant", AntTracking)  # reference train.py:66

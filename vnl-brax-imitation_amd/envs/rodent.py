@@ -112,6 +112,7 @@ class RodentTracking(Env):
     # env-variant knobs (include/vnl.h VNL_ENV_*): RodentTracking's glue by default
     _env_flags = 0
     _done_threshold = 0.0
+    _reward_weights = None  # with ENV_WEIGHTS: (rcom, rvel, rtrunk, rquat, ract, rapp)
     _use_clip_com = False
 
     def _build(self, reference_clip, num_envs, device, _library, _dtype):
@@ -168,6 +169,8 @@ class RodentTracking(Env):
         spec.healthy_z_lo, spec.healthy_z_hi = float(healthy_z_range[0]), float(healthy_z_range[1])
         spec.termination_threshold, spec.body_error_multiplier = self._termination_threshold, self._body_error_multiplier
         spec.flags, spec.done_threshold = int(self._env_flags), float(self._done_threshold)
+        for i, w in enumerate(self._reward_weights or ()):
+            spec.reward_weights[i] = float(w)
         for k, v in self._clip.items():
             setattr(spec, k, fp(v))
         self._env_h = C.c_void_p()
@@ -224,6 +227,7 @@ class RodentTracking(Env):
             healthy_z_hi=self._healthy_z_range[1], termination_threshold=self._termination_threshold,
             body_error_multiplier=self._body_error_multiplier, flags=int(self._env_flags),
             done_threshold=float(self._done_threshold),
+            reward_weights=list(self._reward_weights) if self._reward_weights else None,
         )
 
     def clip_arrays(self, clip: int = 0) -> Dict[str, np.ndarray]:
