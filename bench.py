@@ -125,10 +125,18 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # VNL_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo for the barrier / MAX -- rehearses the N-rank control flow on a
+        # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+        rehearsal = os.environ.get("VNL_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if (distributed and os.environ.get("VNL_BENCH_REHEARSAL") == "1") else dev
 
     import helpers as H
     from vnl_brax_imitation_amd.envs.rodent import RodentTracking
@@ -226,7 +234,7 @@ def main() -> None:
         dt = time.perf_counter() - t0
         base.kernel_events = None
         if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
