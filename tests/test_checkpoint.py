@@ -59,3 +59,74 @@ def test_training_resumes_from_a_checkpoint(tmp_path):
     assert int(ts2.optimizer_state["count"]) == 2 * count0 and ts2.env_steps == 2 * steps0
     assert float(params2[0].count) == 2 * float(params[0].count)  # the normaliser kept accumulating
     assert not torch.equal(params2[1], params[1])
+
+
+def test_reference_brax_pickle_converts_without_jax(tmp_path):
+    """brax.io.model.save_params pickles (RunningStatisticsState, {'params': FrozenDict of jax Arrays}) (reference
+    train.py:154-156).  The converter must read such a file with none of jax / flax / brax importable.  The pickle here is
+    made with stand-in modules under the real module paths (so the stream holds the reference's GLOBAL opcodes), which are
+    removed again before the conversion."""
+    import pickle
+    import sys
+    import types
+
+    net = ppo_networks.make_intention_ppo_networks(795, 232, 30, intention_latent_size=16, encoder_layer_sizes=(32, 24),
+                                                   decoder_layer_sizes=(32, 24), value_hidden_layer_sizes=(32,))
+    flat = net.policy_network.init(torch.Generator().manual_seed(4))
+    tree = checkpoint.to_flax_tree(net.policy_network.layout, flat)
+    rng = np.random.default_rng(0)
+    norm = dict(count=np.float32(1234.0), mean=rng.standard_normal(232).astype(np.float32),
+                summed_variance=rng.random(232).astype(np.float32), std=(0.5 + rng.random(232)).astype(np.float32))
+
+    def reconstruct(fun, args, arr_state, aval_state):  # never called: only its qualified name goes into the stream
+        raise AssertionError
+
+    class FakeJaxArray:
+        def __init__(self, a):
+            self.a = np.asarray(a)
+
+        def __reduce__(self):
+            fun, args, state = self.a.__reduce__()
+            return reconstruct, (fun, args, state, {"weak_type": False})
+
+    class RunningStatisticsState:
+        pass
+
+    class FrozenDict(dict):
+        def __reduce__(self):
+            return FrozenDict, (dict(self),)
+
+    fakes = {"jax._src.array": ("_reconstruct_array", reconstruct), "brax.training.acme.running_statistics":
+             ("RunningStatisticsState", RunningStatisticsState), "flax.core.frozen_dict": ("FrozenDict", FrozenDict)}
+    made = []
+    for mod, (name, obj) in fakes.items():
+        parts = mod.split(".")
+        for i in range(1, len(parts) + 1):
+            m = ".".join(parts[:i])
+            if m not in sys.modules:
+                sys.modules[m] = types.ModuleType(m)
+                made.append(m)
+        setattr(sys.modules[mod], name, obj)
+        obj.__module__, obj.__qualname__ = mod, name
+        obj.__name__ = name
+    try:
+        ns = RunningStatisticsState()
+        for k, v in norm.items():
+            setattr(ns, k, FakeJaxArray(v))
+
+        def wrap(node):
+            return FrozenDict({k: wrap(v) for k, v in node.items()}) if isinstance(node, dict) else FakeJaxArray(node)
+
+        blob = pickle.dumps((ns, {"params": wrap(tree["params"])}))
+    finally:
+        for m in made:
+            del sys.modules[m]
+    assert b"jax._src.array" in blob and b"brax.training.acme.running_statistics" in blob
+    assert "jax" not in sys.modules and "brax" not in sys.modules
+    path = tmp_path / "policy_params"
+    path.write_bytes(blob)
+    n2, flat2 = checkpoint.convert_brax_params(str(path), net, npz_path=str(tmp_path / "converted"))
+    assert torch.equal(flat2, flat)
+    assert float(n2.count) == 1234.0 and np.array_equal(n2.std.numpy(), norm["std"]) and np.array_equal(n2.mean.numpy(), norm["mean"])
+    ck = checkpoint.load_params(str(tmp_path / "converted"), net)
+    assert torch.equal(ck["params"][1], flat) and torch.equal(ck["params"][0].summed_variance, n2.summed_variance)

@@ -102,6 +102,82 @@ def _unflatten(prefix: str, layout: ParamLayout, z) -> torch.Tensor:
     return from_flax_tree(layout, tree)
 
 
+# ---- reference checkpoints (brax.io.model.save_params: pickle.dumps of (RunningStatisticsState, flax params)) -----------
+class _Bag:
+    """Inert stand-in for a pickled dataclass / flax struct: takes its fields, runs no code of the pickled class."""
+
+    def __init__(self, *args, **kwargs):
+        self._args = args
+        self.__dict__.update(kwargs)
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self._state = state
+
+
+def _jax_array(fun, args, arr_state, aval_state):
+    """jax._src.array._reconstruct_array(fun, args, arr_state, aval_state): fun / args rebuild the NumPy ndarray."""
+    arr = fun(*args)
+    arr.__setstate__(arr_state)
+    return np.asarray(arr)
+
+
+class _BraxUnpickler(__import__("pickle").Unpickler):
+    """NumPy reconstruction and plain containers only; every other global (flax structs, FrozenDict, jax Arrays) becomes
+    an inert bag or a NumPy array.  Nothing of jax / flax / brax is imported or executed."""
+
+    _NUMPY = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+              ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._NUMPY:
+            return getattr(__import__(module, fromlist=[name]), name)
+        if (module, name) == ("jax._src.array", "_reconstruct_array"):
+            return _jax_array
+        if (module, name) == ("collections", "OrderedDict"):
+            import collections
+
+            return collections.OrderedDict
+        if name == "FrozenDict":  # flax.core.frozen_dict.FrozenDict(dict)
+            return lambda *a, **k: dict(*a, **k)
+        return _Bag
+
+
+def _as_tree(x):
+    if isinstance(x, _Bag):
+        d = {k: v for k, v in vars(x).items() if not k.startswith("_")}
+        if not d and getattr(x, "_args", None):
+            return _as_tree(x._args[0]) if len(x._args) == 1 else [_as_tree(a) for a in x._args]
+        return {k: _as_tree(v) for k, v in d.items()}
+    if isinstance(x, dict):
+        return {k: _as_tree(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_as_tree(v) for v in x]
+    return x
+
+
+def convert_brax_params(pickle_path: str, ppo_network, npz_path: Optional[str] = None):
+    """A checkpoint of the REFERENCE trainer -- `brax.io.model.save_params(path, (normalizer_params, policy_params))`,
+    reference train.py:154-156,337-338 -- to this package's params `(RunningStatisticsState, policy_flat)`, optionally
+    written as the `.npz` of `save_params`.  The pickle is read with a restricted unpickler (no jax / flax / brax needed or
+    executed); the policy tree must carry the reference's Flax names (`from_flax_tree` checks names and shapes)."""
+    import io
+
+    with open(pickle_path, "rb") as f:
+        obj = _as_tree(_BraxUnpickler(io.BytesIO(f.read())).load())
+    if not (isinstance(obj, (list, tuple)) and len(obj) == 2):
+        raise ValueError("expected the pair (normalizer_params, policy_params)")
+    norm_t, pol_t = obj
+    arr = lambda v: torch.from_numpy(np.array(v, dtype=np.float32))  # noqa: E731
+    norm = running_statistics.RunningStatisticsState(*(arr(norm_t[k]) for k in _NORM))
+    flat = from_flax_tree(ppo_network.policy_network.layout, pol_t if "params" in pol_t else {"params": pol_t})
+    if npz_path:
+        save_params(npz_path, (norm, flat), ppo_network)
+    return norm, flat
+
+
 def load_params(path: str, ppo_network, device=None) -> Dict[str, Any]:
     """-> {'params': (normalizer, policy_flat), and when present 'value', 'optimizer', 'env_steps'}."""
     z = np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False)
