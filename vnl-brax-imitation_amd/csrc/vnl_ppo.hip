@@ -58,8 +58,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   constexpr int BK = BM == 64 ? 32 : 16, LDA = BM + 4, LDB = BN + 4;
   constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NJ = WTN / 32;
   constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;  // float4 per thread per tile
-  __shared__ __align__(16) float As[2][BK][LDA];
-  __shared__ __align__(16) float Bs[2][BK][LDB];
+  // LDS image of an operand slab.  An operand whose k index is contiguous in global memory (A of NN / NT, B of NT) keeps
+  // that orientation -- [row][BK + 4]: float4 stores straight from the float4 loads (no transposing scalar stores, whose
+  // bank conflicts were 33-50 % of these kernels' LDS cycles) and the lane's whole k range of the slab in BK / 8
+  // ds_read_b128.  The other orientation ([k][row + 4]) is read with one ds_read per k-pair as before.  Either way the
+  // MFMA of step j pairs k = j (lanes 0-31) with k = j + BK / 2 (lanes 32-63): any pairing is valid if A and B agree.
+  constexpr bool AK = !TA, BKC = TB;
+  constexpr int LDK = BK + 4;
+  constexpr int A_FLOATS = AK ? BM * LDK : BK * LDA, B_FLOATS = BKC ? BN * LDK : BK * LDB;
+  __shared__ __align__(16) float As[2][A_FLOATS];
+  __shared__ __align__(16) float Bs[2][B_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
@@ -145,23 +153,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       const int idx = tid + 256 * i;
-      if constexpr (!TA) {
+      if constexpr (AK) {
         const int r = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-        As[buf][kq][r] = ra[i].x, As[buf][kq + 1][r] = ra[i].y, As[buf][kq + 2][r] = ra[i].z, As[buf][kq + 3][r] = ra[i].w;
+        *(f32x4*)&As[buf][r * LDK + kq] = ra[i];
       } else {
         const int kk = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
-        *(f32x4*)&As[buf][kk][mq] = ra[i];
+        *(f32x4*)&As[buf][kk * LDA + mq] = ra[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       const int idx = tid + 256 * i;
-      if constexpr (!TB) {
+      if constexpr (!BKC) {
         const int kk = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
-        *(f32x4*)&Bs[buf][kk][nq] = rb[i];
+        *(f32x4*)&Bs[buf][kk * LDB + nq] = rb[i];
       } else {
         const int r = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-        Bs[buf][kq][r] = rb[i].x, Bs[buf][kq + 1][r] = rb[i].y, Bs[buf][kq + 2][r] = rb[i].z, Bs[buf][kq + 3][r] = rb[i].w;
+        *(f32x4*)&Bs[buf][r * LDK + kq] = rb[i];
       }
     }
   };
@@ -180,13 +188,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   for (int kt = 0; kt < nk; kt++) {
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);  // global loads in flight under the MFMAs
     const int kh = lane >> 5, c = lane & 31;
+    constexpr int H = BK / 2;  // k-steps of a slab; this lane's k range is [kh * H, kh * H + H)
+    float av[AK ? MI : 1][AK ? H : 1], bv[BKC ? NJ : 1][BKC ? H : 1];
+    if constexpr (AK) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int q = 0; q < H / 4; q++) {
+          const f32x4 v = *(const f32x4*)&As[buf][(wm * WTM + i * 32 + c) * LDK + kh * H + 4 * q];
+          av[i][4 * q] = v.x, av[i][4 * q + 1] = v.y, av[i][4 * q + 2] = v.z, av[i][4 * q + 3] = v.w;
+        }
+    }
+    if constexpr (BKC) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int q = 0; q < H / 4; q++) {
+          const f32x4 v = *(const f32x4*)&Bs[buf][(wn * WTN + j * 32 + c) * LDK + kh * H + 4 * q];
+          bv[j][4 * q] = v.x, bv[j][4 * q + 1] = v.y, bv[j][4 * q + 2] = v.z, bv[j][4 * q + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < H; t++) {
       float a[MI], b[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; i++) a[i] = As[buf][kk + kh][wm * WTM + i * 32 + c];
+      for (int i = 0; i < MI; i++) {
+        if constexpr (AK) a[i] = av[i][t];
+        else a[i] = As[buf][(t + kh * H) * LDA + wm * WTM + i * 32 + c];
+      }
 #pragma unroll
-      for (int j = 0; j < NJ; j++) b[j] = Bs[buf][kk + kh][wn * WTN + j * 32 + c];
+      for (int j = 0; j < NJ; j++) {
+        if constexpr (BKC) b[j] = bv[j][t];
+        else b[j] = Bs[buf][(t + kh * H) * LDB + wn * WTN + j * 32 + c];
+      }
 #pragma unroll
       for (int i = 0; i < MI; i++)
 #pragma unroll
