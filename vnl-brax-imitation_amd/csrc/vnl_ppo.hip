@@ -184,7 +184,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   // Measured and dropped (tools/ppo_update_bench.py, 0.478 ms per step as is): a second register set so that the global
   // loads of slab kt + 2 are issued before slab kt is computed (0.478); requesting every LDS fragment of a slab before
   // its first MFMA instead of the compiler's read / s_waitcnt / MFMA pairs (0.497); the value MLP's big weight gradient
-  // on a third stream beside the input-gradient GEMM of the same layer (0.58: two chip-filling GEMMs thrash).
+  // on a third stream beside the input-gradient GEMM of the same layer (0.58: two chip-filling GEMMs thrash); slab depth
+  // 64 for the 64 x 64 tile (two workgroups per CU: 0.525) and 16 (0.483) against 32 (0.473).
   for (int kt = 0; kt < nk; kt++) {
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);  // global loads in flight under the MFMAs
     const int kh = lane >> 5, c = lane & 31;
