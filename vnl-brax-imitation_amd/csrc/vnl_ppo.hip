@@ -554,9 +554,19 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* X, const float
 // v[r] = A[r][:] . w + b : one wave per row
 __global__ void __launch_bounds__(256) rowdot_kernel(const float* A, const float* w, const float* b, float* v, int rows, int h) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int r = blockIdx.x * 4 + wv; r < rows; r += gridDim.x * 4) {
+  const bool vec = (h & 3) == 0 && (((uintptr_t)A | (uintptr_t)w) & 15) == 0;
+  for (int r = blockIdx.x * 4 + wv; r < rows; r += gridDim.x * 4) {  // launched with one row per wave
     float s = 0.f;
-    for (int c = lane; c < h; c += 64) s += A[(size_t)r * h + c] * w[c];
+    if (vec) {
+      const f32x4* a4 = (const f32x4*)(A + (size_t)r * h);
+      const f32x4* w4 = (const f32x4*)w;
+      for (int c = lane; c < h / 4; c += 64) {
+        const f32x4 x = a4[c], y = w4[c];
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+    } else {
+      for (int c = lane; c < h; c += 64) s += A[(size_t)r * h + c] * w[c];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) v[r] = s + b[0];
   }
@@ -930,7 +940,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
       x = u->valA[i], ldx = d.out;
     }
     const DenseP& d = u->val[nvl - 1];
-    hipLaunchKernelGGL(rowdot_kernel, dim3(256), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
   }
   // encoder (intention_policy_network.py:20-44)
   {
@@ -998,7 +1008,9 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   {
     const DenseP& dl = u->val[nvl - 1];
     const float* Alast = nvl >= 2 ? u->valA[nvl - 2] : u->obsn;
-    GV.wgrad(Alast, dl.in, u->gb, 1, Gr + dl.w, Gr + dl.b, dl.in, 1, N);  // d w_out = A' gb, d b_out = sum gb
+    // d w_out = A' gb, d b_out = sum gb: a 1025 x 1 product, 16 us as a launch of its own at the head of this chain -- it
+    // joins the intention network's grouped weight-gradient launch on the other stream instead (operands ready since the head)
+    GP.wgrad(Alast, dl.in, u->gb, 1, Gr + dl.w, Gr + dl.b, dl.in, 1, N);
     float *dz = u->dA, *dz_other = u->dB;
     if (nvl >= 2) {
       const int h = u->val[nvl - 2].out;
