@@ -1,0 +1,96 @@
+"""Edge cases of the env entry points: NaN in the inputs (reference envs/rodent.py:216-226: reward / obs through nan_to_num,
+done = 1 when the new pipeline state holds a NaN), a batch of one, ragged batch sizes, argument validation.
+CPU tier on the float32 host build of the kernels; the same checks on the device under -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+
+def _env(B, device="cpu"):
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+
+    if device == "cpu":
+        return H.hostsim_env(B)
+    return RodentTracking(H.reference_clip(), num_envs=B, device=device, **H.env_kwargs())
+
+
+def _inputs(B, seed=5):
+    rng = np.random.default_rng(seed)
+    sf = rng.integers(0, 200, B).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
+    act = np.clip(0.3 * rng.standard_normal((B, 30)), -1, 1).astype(np.float32)
+    return torch.from_numpy(sf), torch.from_numpy(noise), torch.from_numpy(act)
+
+
+def _snapshot(st):
+    ps = st.pipeline_state
+    return {k: v.detach().cpu().clone() for k, v in dict(qpos=ps.qpos, qvel=ps.qvel, warm=ps.qacc_warmstart, obs=st.obs,
+                                                         traj=st.info["traj"], reward=st.reward, done=st.done).items()}
+
+
+def _nan_action_case(device):
+    B, bad = 8, 2
+    sf, noise, act = _inputs(B)
+    env = _env(B, device)
+    clean = _snapshot(env.step(env.reset(start_frame=sf, noise=noise), act))
+    act_nan = act.clone()
+    act_nan[bad, 3] = float("nan")
+    got = _snapshot(env.step(env.reset(start_frame=sf, noise=noise), act_nan))
+    # the poisoned env: done, finite reward and observation (nan_to_num), NaN left in the physics state as in the reference
+    assert got["done"][bad] == 1.0 and torch.isfinite(got["reward"][bad]) and torch.isfinite(got["obs"][bad]).all()
+    assert torch.isnan(got["qvel"][bad]).any()
+    # every other env is untouched, bit for bit
+    keep = [i for i in range(B) if i != bad]
+    for k in clean:
+        assert torch.equal(got[k][keep], clean[k][keep]), k
+    # the oracle takes the same decisions on the same inputs
+    o = H.make_oracle(env, "f32")
+    ost = o.env_reset(sf.numpy(), noise.numpy())
+    o.env_step(ost, act_nan.numpy())
+    assert ost["done"][bad] == 1.0 and np.isfinite(ost["reward"][bad]) and np.isfinite(ost["obs"][bad]).all()
+    assert np.array_equal(got["done"].numpy(), ost["done"].astype(np.float32))
+
+
+def _ragged_sizes_case(device):
+    sf, noise, act = _inputs(64)
+    ref = _snapshot((lambda e: e.step(e.reset(start_frame=sf, noise=noise), act))(_env(64, device)))
+    for B in (1, 3, 17):  # one env; sizes that are not multiples of anything the kernels tile by
+        env = _env(B, device)
+        got = _snapshot(env.step(env.reset(start_frame=sf[:B], noise=noise[:B]), act[:B]))
+        for k in ref:
+            assert torch.equal(got[k], ref[k][:B]), (B, k)
+
+
+def _validation_case(device):
+    env = _env(4, device)
+    sf, noise, act = _inputs(4)
+    st = env.reset(start_frame=sf, noise=noise)
+    with pytest.raises(ValueError):
+        env.step(st, act[:3])  # wrong batch
+    with pytest.raises(ValueError):
+        env.step(st, act[:, :29])  # wrong action width
+    # start frames beyond the clip are clamped like a JAX gather (SURVEY C.4/C.5 semantics), not an error
+    far = torch.full((4,), 10_000, dtype=torch.int32)
+    st = env.reset(start_frame=far, noise=noise)
+    assert torch.isfinite(st.obs).all() and (st.info["cur_frame"] == 10_000).all()
+
+
+def test_nan_action_is_contained_to_its_env():
+    _nan_action_case("cpu")
+
+
+def test_batch_of_one_and_ragged_batch_sizes():
+    _ragged_sizes_case("cpu")
+
+
+def test_argument_validation_and_out_of_range_frames():
+    _validation_case("cpu")
+
+
+@pytest.mark.gpu
+def test_edge_cases_on_the_device():
+    _nan_action_case("cuda:0")
+    _ragged_sizes_case("cuda:0")
+    _validation_case("cuda:0")

@@ -2232,7 +2232,8 @@ struct EnvWave {
     const vreal* ac = action + (size_t)e * m.nu;
     VNL_FOR(i, m.nu) {
       vreal c = ac[i];
-      if (m.act_limited[i]) c = fmin(fmax(c, m.act_lo[i]), m.act_hi[i]);
+      // jnp.clip semantics: a NaN control stays NaN (and ends the episode below); fmin / fmax would swallow it
+      if (m.act_limited[i]) c = c < m.act_lo[i] ? m.act_lo[i] : (c > m.act_hi[i] ? m.act_hi[i] : c);
       s[L.ctrl + i] = c;
     }
     VNL_SYNC();
