@@ -94,3 +94,42 @@ def test_edge_cases_on_the_device():
     _nan_action_case("cuda:0")
     _ragged_sizes_case("cuda:0")
     _validation_case("cuda:0")
+
+
+def test_non_default_env_parameters_match_the_oracle():
+    """Constructor parameters away from configs/env_config.yaml's values: 3 substeps, 3 reference frames, sub-clip 4, a
+    tight healthy band (some envs fall out of it), a strict termination threshold with a body-error multiplier.  float64
+    build of the kernels vs the float64 oracle, resynchronised every control step (tests/test_hostsim_parity.py: why)."""
+    import parity as P
+
+    B = 12
+    env = H.hostsim_env(B, "double", n_frames=3, ref_traj_length=3, sub_clip_length=4, healthy_z_range=(0.068, 0.10),
+                        termination_threshold=0.3, body_error_multiplier=2.5)
+    assert env.traj_size == 3 * (env.traj_size // 3) and env._n_frames == 3
+    o = H.make_oracle(env, "f64")
+    rng = np.random.default_rng(11)
+    sf = rng.integers(0, 200, B).astype(np.int32)
+    noise = 5e-3 * rng.standard_normal((B, 74))
+    st = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    ost = o.env_reset(sf, noise)
+    assert H.scaled_err(st.obs.numpy(), ost["obs"]) < 1e-12 and H.scaled_err(st.info["traj"].numpy(), ost["traj"]) < 1e-11
+    assert H.scaled_err(st.info["termination_error"].numpy(), ost["termination_error"]) < 1e-7  # (0.3f != 0.3)
+    seen_done, seen_alive = False, False
+    for step in range(5):
+        ost = P.oracle_state_from(env, o, st)
+        act = np.clip(0.5 * rng.standard_normal((B, 30)), -1, 1)
+        st = env.step(st, torch.from_numpy(act))
+        o.env_step(ost, act)
+        e = P.state_errors(st, ost)
+        assert max(v.max() for v in e.values()) < 1e-8, {k: v.max() for k, v in e.items()}
+        m = np.stack([st.metrics[k].numpy() for k in st.metrics], 1)
+        # (thresholds and the z band are float32 in the C-ABI)
+        assert np.abs(m - ost["metrics"]).max() < 1e-7 and np.abs(st.reward.numpy() - ost["reward"]).max() < 1e-7
+        assert np.array_equal(st.done.numpy(), ost["done"]), (step, st.done.numpy(), ost["done"])
+        assert np.array_equal(st.info["sub_clip_frame"].numpy(), ost["sub_clip_frame"])
+        assert H.scaled_err(st.info["traj"].numpy(), ost["traj"]) < 1e-9
+        seen_done |= bool((st.done.numpy() == 1).any())
+        seen_alive |= bool((st.done.numpy() == 0).any())
+        if step >= 3:
+            assert (st.done.numpy() == 1).all()  # sub_clip_length 4 reached (rodent.py:207-215)
+    assert seen_done and seen_alive  # both outcomes of the termination logic were exercised
