@@ -1777,25 +1777,34 @@ struct EnvWave {
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
     vreal cost = fresh().constraint_force() + gauss;
     vreal prev_cost = INFINITY;
+    // The three dot products the iteration's head needs -- |grad|^2, |search|^2 and grad . Mgrad -- are accumulated in the
+    // loops that PRODUCE those vectors (same lane order, same wave sum: the same bits as separate passes), not in passes
+    // of their own at the top of every iteration.
+    vreal gg = vreal(0.), ss = vreal(0.), gp = vreal(0.);
     VNL_FOR(d, nv) {
       vreal g = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
       s[L.grad + d] = g, s[L.Mgrad + d] = g;
+      gg += g * g;
     }
+    gg = vnl_wave_sum(gg);
     VNL_SYNC();
     fresh().solve_inplace(L.Mgrad);
     VNL_FOR(d, nv) {
-      s[L.search + d] = -s[L.Mgrad + d];
-      s[L.mv + d] = -s[L.grad + d];  // M search
+      const vreal mg = s[L.Mgrad + d], gr = s[L.grad + d];
+      s[L.search + d] = -mg;
+      s[L.mv + d] = -gr;  // M search
+      ss += mg * mg, gp += gr * mg;
     }
+    ss = vnl_wave_sum(ss), gp = vnl_wave_sum(gp);
     VNL_SYNC();
     VNL_PROF(15);
 
     for (int it = 0; it < m.iterations; it++) {
       vreal improvement = (prev_cost - cost) / m.scale;
-      vreal gradient = sqrt(vdot(L.grad, L.grad)) / m.scale;
+      vreal gradient = sqrt(gg) / m.scale;
       if (improvement < m.tolerance || gradient < m.tolerance) break;
       // ---- line search
-      vreal smag = sqrt(vdot(L.search, L.search)) * m.scale;
+      vreal smag = sqrt(ss) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
       VNL_PROF(16);
       fresh().jac_mul(L.search, L.jv, false);
@@ -1825,8 +1834,7 @@ struct EnvWave {
       for_live_rows([&](int r) { s[L.Jaref + r] += alpha * s[L.jv + r]; });
       VNL_SYNC();
       VNL_PROF(20);
-      // ---- constraint + gradient update
-      vreal gp = vdot(L.grad, L.Mgrad);
+      // ---- constraint + gradient update   (gp = grad . Mgrad of the vectors as they stand: carried, see above)
       vreal g = vreal(0.);
       VNL_FOR(d, nv) g += (s[L.Ma + d] - s[L.smooth + d]) * (s[L.qacc + d] - s[L.qacc_smooth + d]);
       g = vnl_wave_sum(g);
@@ -1835,24 +1843,31 @@ struct EnvWave {
       VNL_PROF(22);
       prev_cost = cost, cost = ncost, gauss = vreal(0.5) * g;
       vreal d1 = vreal(0.);
+      gg = vreal(0.);
       VNL_FOR(d, nv) {
         vreal gn = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
         d1 += gn * s[L.Mgrad + d];
         s[L.grad + d] = gn, s[L.tmp + d] = gn;
+        gg += gn * gn;
       }
-      d1 = vnl_wave_sum(d1);
+      d1 = vnl_wave_sum(d1), gg = vnl_wave_sum(gg);
       VNL_SYNC();
       VNL_PROF(23);
       fresh().solve_inplace(L.tmp);
       VNL_PROF(24);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
+      gp = d2;  // grad . Mgrad with Mgrad := tmp below
+      ss = vreal(0.);
       VNL_FOR(d, nv) {
         vreal mg = s[L.tmp + d];
         s[L.Mgrad + d] = mg;
-        s[L.search + d] = -mg + beta * s[L.search + d];
+        const vreal sn = -mg + beta * s[L.search + d];
+        s[L.search + d] = sn;
         s[L.mv + d] = -s[L.grad + d] + beta * s[L.mv + d];
+        ss += sn * sn;
       }
+      ss = vnl_wave_sum(ss);
       VNL_SYNC();
       VNL_PROF(25);
     }
