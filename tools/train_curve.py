@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--eval-envs", type=int, default=512)
     ap.add_argument("--updates", type=int, default=None)
+    ap.add_argument("--backend", default="auto", help="minibatch step: hip (hand-written) | torch (autograd) | auto")
+    ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B = args.envs
@@ -51,7 +53,8 @@ def main():
               unroll_length=unroll, batch_size=B // nmb, num_minibatches=nmb,
               num_updates_per_batch=args.updates or c["num_updates_per_batch"], num_evals=args.evals,
               normalize_observations=True, network_factory=nf, num_eval_envs=args.eval_envs, eval_env=eval_env,
-              kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"], progress_fn=progress)
+              kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"], progress_fn=progress,
+              update_backend=args.backend, seed=args.seed)
 
 
 if __name__ == "__main__":

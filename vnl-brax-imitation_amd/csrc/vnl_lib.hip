@@ -1038,8 +1038,20 @@ extern "C" int vnl_gather_rows(const vnl_gather_desc* d, void* stream) {
 __global__ void __launch_bounds__(VNL_ADAM_THREADS) vnl_adam_kernel(float* p, const float* g, float* mu, float* nu,
                                                                     const long long* count, long long n, double lr_,
                                                                     double b1_, double b2_, double eps_) {
+  // the two bias corrections: one thread of the block evaluates the double-precision powers (they were most of this
+  // kernel's time when every thread did), the others pick them up from LDS
+#if VNL_ADAM_THREADS > 1
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)count[0];
+    bc[0] = (float)(1.0 - pow(b1_, t)), bc[1] = (float)(1.0 - pow(b2_, t));
+  }
+  __syncthreads();
+  const float bc1 = bc[0], bc2 = bc[1];
+#else
   const double t = (double)count[0];
   const float bc1 = (float)(1.0 - pow(b1_, t)), bc2 = (float)(1.0 - pow(b2_, t));
+#endif
   const float b1 = (float)b1_, b2 = (float)b2_, omb1 = (float)(1.0 - b1_), omb2 = (float)(1.0 - b2_);
   const float lr = (float)lr_, eps = (float)eps_;
   for (long long i = (long long)blockIdx.x * VNL_ADAM_THREADS + threadIdx.x; i < n;
@@ -1055,7 +1067,7 @@ extern "C" int vnl_adam_step(float* params, const float* grads, float* mu, float
                              double lr, double b1, double b2, double eps, void* stream) {
   if (!params || !grads || !mu || !nu || !count || n <= 0) return fail(VNL_ERR_ARG, "vnl_adam_step: null argument");
   long long blocks = (n + VNL_ADAM_THREADS - 1) / VNL_ADAM_THREADS;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(vnl_adam_kernel, dim3((unsigned)blocks), dim3(VNL_ADAM_THREADS), 0, (hipStream_t)stream, params,
                      grads, mu, nu, (const long long*)count, (long long)n, lr, b1, b2, eps);
   HIPCHK(hipGetLastError());
