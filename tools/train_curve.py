@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--updates", type=int, default=None)
     ap.add_argument("--backend", default="auto", help="minibatch step: hip (hand-written) | torch (autograd) | auto")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--reset-info", action="store_true", help="reset info (frame counters, traj) on auto-reset: the fix of the "
+                    "reference's quirk C.20 (without it every env is `done` at every step after its first ten)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B = args.envs
@@ -54,7 +56,7 @@ def main():
               num_updates_per_batch=args.updates or c["num_updates_per_batch"], num_evals=args.evals,
               normalize_observations=True, network_factory=nf, num_eval_envs=args.eval_envs, eval_env=eval_env,
               kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"], progress_fn=progress,
-              update_backend=args.backend, seed=args.seed)
+              update_backend=args.backend, seed=args.seed, reset_info_on_autoreset=args.reset_info)
 
 
 if __name__ == "__main__":
