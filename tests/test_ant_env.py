@@ -123,3 +123,38 @@ def test_ant_env_on_gpu():
     for name, v in gerr.items():
         assert (v <= np.maximum(1e-5, 10 * gdev[name])).all(), (name, v.max(), gdev[name].max())
     assert torch.equal(st.obs, torch.cat((st.info["traj"], st.pipeline_state.qpos, st.pipeline_state.qvel), 1))
+
+
+def _config0_rollout(device, steps=250, B=64, seed=0):
+    """BASELINE.json configs[0]: envs/ant.py random-action rollout, 64 envs (actions clip(0.3 N(0, I), -1, 1),
+    seed 0, 250 control steps; pass = runs, finite, deterministic)."""
+    from vnl_brax_imitation_amd.envs.wrappers import wrap
+
+    env = _env(B, device=device)
+    w = wrap(env, episode_length=20)
+    st = w.reset(seed)
+    g = torch.Generator().manual_seed(seed)
+    rew, dones = [], 0.0
+    for _ in range(steps):
+        a = torch.clamp(0.3 * torch.randn((B, 8), generator=g), -1.0, 1.0).to(env.device)
+        st = w.step(st, a)
+        rew.append(st.reward.detach().cpu().clone())
+        dones += float(st.done.sum())
+    assert torch.isfinite(st.obs).all() and torch.isfinite(torch.stack(rew)).all()
+    return torch.stack(rew), st.obs.detach().cpu().clone(), dones
+
+
+def test_config0_ant_random_action_rollout_runs_finite_and_deterministic():
+    r1, o1, d1 = _config0_rollout("cpu")
+    r2, o2, d2 = _config0_rollout("cpu")
+    assert torch.equal(r1, r2) and torch.equal(o1, o2) and d1 == d2  # deterministic
+    assert d1 > 0 and float(r1.abs().max()) > 0  # episodes end (20-step truncation / falls) and rewards are produced
+    assert o1.shape == (64, 5 * (2 * 10 * 3 + 3 + 8) + 15 + 14)
+
+
+@pytest.mark.gpu
+def test_config0_ant_random_action_rollout_on_gpu():
+    r1, o1, d1 = _config0_rollout("cuda:0")
+    r2, o2, d2 = _config0_rollout("cuda:0")
+    assert torch.equal(r1, r2) and torch.equal(o1, o2) and d1 == d2
+    assert d1 > 0
