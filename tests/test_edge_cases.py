@@ -133,3 +133,28 @@ def test_non_default_env_parameters_match_the_oracle():
         if step >= 3:
             assert (st.done.numpy() == 1).all()  # sub_clip_length 4 reached (rodent.py:207-215)
     assert seen_done and seen_alive  # both outcomes of the termination logic were exercised
+
+
+def test_training_step_on_a_multi_clip_env():
+    """BASELINE configs[3]'s code path at toy size: the trainer on an env whose clip container holds several clips, clip
+    ids drawn per env at reset and carried through auto-resets (reference stub envs/rodent.py:473-475)."""
+    import functools
+
+    from vnl_brax_imitation_amd.ppo_imitation import ppo_networks
+    from vnl_brax_imitation_amd.ppo_imitation import train as ppo
+    from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
+
+    multi = pp.synthesize_clips(H.model(), H.golden_qpos(), 3, seed=0)
+    env = H.hostsim_env(8, reference_clip=multi)
+    assert env._num_clips == 3
+    st = env.reset(7)
+    ids = st.info["clip_id"].clone()
+    assert len(set(ids.tolist())) > 1  # several clips in one batch
+    nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=16, encoder_layer_sizes=(32, 24),
+                           decoder_layer_sizes=(32, 24), value_hidden_layer_sizes=(32,))
+    log = []
+    ppo.train(environment=env, num_timesteps=2 * 8 * 5, episode_length=150, num_envs=8, learning_rate=1e-3, entropy_cost=1e-3,
+              discounting=0.99, unroll_length=5, batch_size=2, num_minibatches=4, num_updates_per_batch=1, num_evals=1,
+              normalize_observations=True, network_factory=nf, num_eval_envs=0, eval_env=None, seed=1,
+              progress_fn=lambda s, m: log.append(m))
+    assert log and np.isfinite(log[-1]["training/total_loss"])
