@@ -157,6 +157,10 @@ int vnl_env_reset(vnl_env*, const int32_t* start_frame, const float* noise, cons
 
 /* step: action [num_envs][nu]; state updated in place. */
 int vnl_env_step(vnl_env*, const float* action, const vnl_state* state, void* stream);
+/* Forward kinematics only (reference preprocessing/mjx_preprocess.py:85-107: `mjx.kinematics` scanned over the frames of a
+ * clip): env e takes row e of qpos [num_envs][nq] and fills state->xpos, xquat, subtree_com1 and the
+ * normalised root quaternion in state->qpos[e][3..7); nothing else of the state is touched. */
+int vnl_env_fk(vnl_env* env, const float* qpos, const vnl_state* state, void* stream);
 
 /* Bisection hooks.  The per-env working set lives in LDS; with debug on, every reset/step
  * also copies it to a device dump [num_envs][row_stride]: enable = 1 at the end of the kernel,

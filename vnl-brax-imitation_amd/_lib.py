@@ -136,7 +136,7 @@ class PPOHParams(C.Structure):  # include/vnl.h: vnl_ppo_hparams
 
 EXPORTS = (
     "vnl_last_error", "vnl_version", "vnl_model_create", "vnl_model_destroy", "vnl_env_create", "vnl_env_destroy",
-    "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
+    "vnl_env_dims", "vnl_env_reset", "vnl_env_step", "vnl_env_fk", "vnl_env_debug", "vnl_env_scratch", "vnl_policy_create", "vnl_policy_destroy",
     "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step", "vnl_gather_rows",
     "vnl_ppo_update_create", "vnl_ppo_update_destroy", "vnl_ppo_update_num_params", "vnl_ppo_update_buffer",
     "vnl_ppo_minibatch_grad",
@@ -161,6 +161,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vnl_env_dims.argtypes = [vp, C.POINTER(Dims)]
     lib.vnl_env_reset.argtypes = [vp, vp, vp, C.POINTER(StatePtrs), vp]
     lib.vnl_env_step.argtypes = [vp, vp, C.POINTER(StatePtrs), vp]
+    lib.vnl_env_fk.argtypes = [vp, vp, C.POINTER(StatePtrs), vp]
     lib.vnl_env_debug.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.vnl_env_scratch.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.vnl_rollout_post.argtypes = [C.POINTER(PostDesc), C.c_int32, vp]

@@ -2155,6 +2155,21 @@ struct EnvWave {
   VNL_HD int* trace_of(int* base, int f) const {
     return base ? base + ((size_t)e * ev.n_frames + f) * VNL_TRACE_INTS : nullptr;
   }
+  // Forward kinematics only, of a caller-supplied qpos row per env: smooth.kinematics + the root's subtree centre of mass.
+  // The batched FK of clip preprocessing (reference preprocessing/mjx_preprocess.py:85-107 scans mjx.kinematics over the
+  // frames of a clip): xpos / xquat / subtree_com1 of the state buffers are the outputs.
+  VNL_HD void fk(const vreal* qpos_in) const {
+    load_tables();
+    const vreal* q = qpos_in + (size_t)e * m.nq;
+    VNL_FOR(k, m.nq) s[L.qpos + k] = q[k];
+    VNL_FOR(d, m.nv) s[L.qvel + d] = vreal(0.);
+    VNL_SYNC();
+    fresh().kinematics();
+    fresh().body_inertias(true);
+    VNL_FOR(i, 3) st.com1[(size_t)e * 3 + i] = s[L.com + i];
+    VNL_FOR(k, 4) st.qpos[(size_t)e * m.nq + 3 + k] = s[L.qpos + 3 + k];  // the root quaternion as kinematics normalised it
+  }
+
   VNL_HD void reset(const int* start_frame, const vreal* noise, int* trace_base) const {
     load_tables();
     int clip = st.clip_id[e], sf = start_frame[e];

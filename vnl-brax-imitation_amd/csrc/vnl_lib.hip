@@ -705,6 +705,13 @@ __global__ void __launch_bounds__(64) VNL_KERNEL_ATTR vnl_reset_kernel(const Ker
   if (dump) w.dump(dump);
 }
 
+__global__ void __launch_bounds__(64) vnl_fk_kernel(const KernelConsts* kc, DevState st, const vreal* qpos) {
+  VNL_LDS_DECL(lds);
+  const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
+  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
+  w.fk(qpos);
+}
+
 static int to_dev_state(const vnl_state* s, DevState* d) {
   const void* ptrs[] = {s->qpos, s->qvel, s->act, s->qacc_warmstart, s->xpos, s->xquat, s->subtree_com1,
                         s->qfrc_actuator, s->obs, s->reward, s->done, s->metrics, s->traj, s->termination_error,
@@ -732,6 +739,19 @@ extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const flo
   hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
                      (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr,
                      env->debug ? env->trace : nullptr);
+  HIPCHK(hipGetLastError());
+  return VNL_OK;
+}
+
+extern "C" int vnl_env_fk(vnl_env* env, const float* qpos, const vnl_state* state, void* stream) {
+  if (!env || !qpos || !state) return fail(VNL_ERR_ARG, "vnl_env_fk: null argument");
+  DevState ds;
+  int rc = to_dev_state(state, &ds);
+  if (rc != VNL_OK) return rc;
+  DeviceGuard guard(env->device);
+  if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
+  hipLaunchKernelGGL(vnl_fk_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream, (const KernelConsts*)env->kc, ds,
+                     (const vreal*)qpos);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

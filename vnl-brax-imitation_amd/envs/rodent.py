@@ -305,6 +305,21 @@ class RodentTracking(Env):
         self._hold = (a,)
         return state
 
+    def forward_kinematics(self, qpos: torch.Tensor, out: Optional[State] = None) -> State:
+        """`mjx.kinematics` of one qpos row per env (B, nq) on the device (vnl_env_fk): returns a State whose
+        pipeline_state.xpos / xquat / subtree_com_root are filled and whose qpos carries the normalised root quaternion.
+        Used by the device route of clip preprocessing (preprocessing/mjx_preprocess.py: process_qpos(..., fk=...))."""
+        B, nq = self.num_envs, int(self.dims.nq)
+        if tuple(qpos.shape) != (B, nq):
+            raise ValueError(f"qpos must be ({B},{nq}), got {tuple(qpos.shape)}")
+        state = out if out is not None else self._alloc_state()
+        q = qpos.to(device=self.device, dtype=self._dtype).contiguous()
+        state.pipeline_state.qpos.copy_(q)
+        p = self._ptrs(state)
+        _lib.check(self._L, self._L.vnl_env_fk(self._env_h, q.data_ptr(), C.byref(p), self._stream()))
+        self._hold = (q,)
+        return state
+
     # --- bisection hook -----------------------------------------------------------------------
     def debug(self, mode=True) -> None:
         """Bisection hooks.  mode 1 (True): every reset/step also dumps the per-env LDS image at the end of the

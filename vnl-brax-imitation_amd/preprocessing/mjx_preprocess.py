@@ -125,10 +125,56 @@ def forward_kinematics_batch(model: mjcf.CompiledModel, qpos: np.ndarray):
     return q, xpos, xquat
 
 
+def forward_kinematics_device(model: mjcf.CompiledModel, qpos: np.ndarray, device="cuda", chunk: int = 4096, _library=None):
+    """The same as forward_kinematics_batch on the GPU (float32): the frames go through `vnl_env_fk`, one frame per
+    wavefront, `chunk` frames per launch (the batched FK kernel of SURVEY 8(f) f1).  Returns (qpos with normalised root
+    quaternion, xpos (N, nbody, 3), xquat (N, nbody, 4), subtree centre of mass of the root body (N, 3))."""
+    import torch
+
+    from ..envs.rodent import RodentTracking
+
+    q = np.ascontiguousarray(qpos, dtype=np.float32)
+    N, nq = q.shape
+    nbody, names = int(model.scalars["nbody"]), model.names
+    B = min(int(chunk), N)
+    z = lambda *s: np.zeros(s, dtype=np.float32)  # noqa: E731  (a one-frame placeholder clip: FK reads no clip data)
+    nj = nq - 7
+    dummy = ReferenceClip(position=z(1, 3), quaternion=np.tile(np.array([1, 0, 0, 0], np.float32), (1, 1)), joints=z(1, nj),
+                          body_positions=z(1, nbody, 3), body_quaternions=z(1, nbody, 4), velocity=z(1, 3),
+                          angular_velocity=z(1, 3), joints_velocity=z(1, nj), center_of_mass=z(1, 3))
+    body = [n for n in names["body"] if n != "world"]
+    env = RodentTracking(dummy, end_eff_names=[], appendage_names=[], walker_body_names=body[:1], joint_names=[],
+                         center_of_mass=body[0], model=model, clip_length=1, sub_clip_length=1, ref_traj_length=1,
+                         num_envs=B, device=device, _library=_library)
+    out_q, xpos, xquat, com = q.copy(), z(N, nbody, 3), z(N, nbody, 4), z(N, 3)
+    st = None
+    for a in range(0, N, B):
+        rows = q[a:a + B]
+        n = len(rows)
+        if n < B:
+            rows = np.concatenate([rows, np.repeat(rows[-1:], B - n, axis=0)])
+        st = env.forward_kinematics(torch.from_numpy(rows), out=st)
+        ps = st.pipeline_state
+        out_q[a:a + n, 3:7] = ps.qpos[:n, 3:7].cpu().numpy()
+        xpos[a:a + n] = ps.xpos[:n].reshape(n, nbody, 3).cpu().numpy()
+        xquat[a:a + n] = ps.xquat[:n].reshape(n, nbody, 4).cpu().numpy()
+        com[a:a + n] = ps.subtree_com_root[:n].cpu().numpy()
+    return out_q, xpos, xquat, com
+
+
 def process_qpos(model: mjcf.CompiledModel, mocap_qpos: np.ndarray, max_qvel: float = 20.0,
-                 dt: float = 0.02) -> ReferenceClip:
-    """Feature extraction for one clip given its (T, nq) qpos rows (mjx_preprocess.py:85-107,110-134)."""
+                 dt: float = 0.02, fk_device=None) -> ReferenceClip:
+    """Feature extraction for one clip given its (T, nq) qpos rows (mjx_preprocess.py:85-107,110-134).  `fk_device`
+    ("cuda", ...): run the forward kinematics on the GPU (forward_kinematics_device) instead of the float64 NumPy pass."""
     mocap_qpos = np.asarray(mocap_qpos, dtype=np.float32)
+    if fk_device is not None:
+        qn, xpos, xquat, com = forward_kinematics_device(model, mocap_qpos, device=fk_device)
+        padded = np.concatenate([mocap_qpos, mocap_qpos[-1:]], axis=0)
+        qvel = compute_velocity_from_kinematics(padded, dt)
+        qvel[:, 6:] = np.clip(qvel[:, 6:], -max_qvel, max_qvel)
+        return ReferenceClip(
+            position=qn[:, :3], quaternion=qn[:, 3:7], joints=qn[:, 7:], body_positions=xpos, body_quaternions=xquat,
+            velocity=qvel[:, :3], angular_velocity=qvel[:, 3:6], joints_velocity=qvel[:, 6:], center_of_mass=com)
     qn, xpos, xquat = forward_kinematics_batch(model, mocap_qpos.astype(np.float64))
     qn, xpos, xquat = qn.astype(np.float32), xpos.astype(np.float32), xquat.astype(np.float32)
     padded = np.concatenate([mocap_qpos, mocap_qpos[-1:]], axis=0)
