@@ -41,7 +41,10 @@ def test_hip_policy_matches_torch_and_numpy(B):
     raw = dist.sample_no_postprocessing(lg, eps_a)
     assert torch.allclose(ex["raw_action"].cpu(), raw, atol=1e-5)
     assert torch.allclose(act.cpu(), torch.tanh(raw), atol=1e-5)
-    assert torch.allclose(ex["log_prob"].cpu(), dist.log_prob(lg, raw), atol=2e-3, rtol=1e-4)
+    lp_ref = dist.log_prob(lg.double(), raw.double())  # float64 elementwise math on the kernel's own logits / raw actions
+    lp_err = float((ex["log_prob"].cpu().double() - lp_ref).abs().max() / lp_ref.abs().max())
+    print(f"policy log_prob max error relative to its scale ({float(lp_ref.abs().max()):.1f}): {lp_err:.2e}")
+    assert lp_err < 2e-6, lp_err  # a sum of 30 float32 terms of O(1..10)
     # deterministic mode
     act_d, ex_d = hp.forward(d(flat), d(st.mean), d(st.std), d(traj), d(obs), d(eps_l), None, deterministic=True)
     assert torch.allclose(act_d.cpu(), torch.tanh(lg[:, :30]), atol=1e-5)
@@ -63,5 +66,10 @@ def test_make_policy_uses_hip_kernel_on_gpu():
     assert set(e1) == set(e2) == {"log_prob", "rand_log_prob", "raw_action", "logits"}
     assert torch.allclose(e1["logits"], e2["logits"], atol=2e-4) and torch.allclose(a1, a2, atol=2e-4)
     # same generator, same draw order: the kernel's rand_log_prob is that of the same random action
-    assert torch.allclose(e1["rand_log_prob"], e2["rand_log_prob"], atol=5e-3, rtol=2e-4)
-    assert torch.allclose(e1["log_prob"], e2["log_prob"], atol=5e-3, rtol=2e-4)
+    # (two float32 implementations of the network: the logits differ by ~5e-6, and the log-prob's sensitivity to them is
+    # |d log_prob / d logits| ~ z / scale, up to ~1e2 for a random action five standard deviations out)
+    sc = float(e2["log_prob"].abs().max())
+    for k in ("rand_log_prob", "log_prob"):
+        err = float((e1[k] - e2[k]).abs().max()) / max(float(e2[k].abs().max()), 1.0)
+        print(f"{k}: hip vs torch max error relative to its scale: {err:.2e}")
+        assert err < 2e-5, (k, err)
