@@ -116,3 +116,20 @@ def test_hand_written_gradient_stays_exact_along_training():
     assert r["worst rel err"] < 1e-4, (r["worst tensor"], r["worst rel err"])
     for a, b in zip(r["losses hip"][:5], r["losses f64"][:5]):
         assert abs(a - b) <= 1e-5 * max(abs(b), abs(r["losses f64"][0])), (r["losses hip"], r["losses f64"])
+
+
+def test_full_size_training_step_on_one_gpu():
+    """BASELINE configs[4]'s per-GPU share: 4096 envs, unroll 20, reference network sizes, 32 minibatches of 128 trajectories
+    (2560 samples); two updates per batch instead of sixteen to keep the test short.  The hand-written update inside the
+    captured graph, finite metrics, and the step count the reference's bookkeeping gives."""
+    import os
+    import subprocess
+    import sys
+    import json
+
+    cmd = [sys.executable, os.path.join(H.ROOT, "tools", "train_bench.py"), "--steps", "2", "--updates", "2", "--backend", "hip"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["env_steps"] == 2 * 4096 * 20 and np.isfinite(r["total_loss"]) and np.isfinite(r["v_loss"]) and r["training/sps"] > 0
+    print(f"\n[full-size training step] {r['training/sps']:.0f} env-steps/s with 2 updates per batch (graph capture included)")
