@@ -610,23 +610,30 @@ __global__ void __launch_bounds__(256) latent_bwd_kernel(const float* dD0, int l
 // metrics["prediction_corr"] (intention_losses.py:186-188): the mean of jnp.corrcoef over the 2T rows [vs ; reward *
 // scaling], each a variable with B observations.  One workgroup: centred rows in LDS, then the (2T)^2 normalised dot
 // products, clamped to [-1, 1] as jnp.corrcoef does; a constant row gives NaN, as there.
-__global__ void __launch_bounds__(256) prediction_corr_kernel(const float* vs, const float* reward, float scale, int T, int B,
+#define VNL_CORR_THREADS 1024 /* one workgroup; sixteen waves so that the LDS latency of the pair loop is hidden */
+__global__ void __launch_bounds__(VNL_CORR_THREADS) prediction_corr_kernel(const float* vs, const float* reward, float scale, int T, int B,
                                                               float* out) {
   extern __shared__ float xs[];  // [2T][B] centred, then [2T] norms
-  __shared__ float red[256];
+  __shared__ float red[VNL_CORR_THREADS];
   const int R = 2 * T, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   float* nrm = xs + (size_t)R * B;
-  for (int r = w; r < R; r += 4) {
-    const float* src = r < T ? vs + (size_t)r * B : reward + (size_t)(r - T) * B;
-    const float k = r < T ? 1.f : scale;
+  // rows into LDS first, every load of the block in flight at once (ten rows per wave, one after the other, each with two
+  // passes over global memory, was 30 of this kernel's 36 us); then the means / norms from LDS
+  for (int e = tid; e < R * B; e += VNL_CORR_THREADS) {
+    const int r = e / B, c = e - r * B;
+    xs[e] = r < T ? vs[(size_t)r * B + c] : reward[(size_t)(r - T) * B + c] * scale;
+  }
+  __syncthreads();
+  for (int r = w; r < R; r += VNL_CORR_THREADS / 64) {
+    float* x = xs + (size_t)r * B;
     float s1 = 0.f;
-    for (int c = lane; c < B; c += 64) s1 += src[c] * k;
+    for (int c = lane; c < B; c += 64) s1 += x[c];
     for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
     const float mu = s1 / (float)B;
     float q = 0.f;
     for (int c = lane; c < B; c += 64) {
-      const float d = src[c] * k - mu;
-      xs[(size_t)r * B + c] = d;
+      const float d = x[c] - mu;
+      x[c] = d;
       q += d * d;
     }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
@@ -634,22 +641,36 @@ __global__ void __launch_bounds__(256) prediction_corr_kernel(const float* vs, c
   }
   __syncthreads();
   float acc = 0.f;
-  for (int pq = tid; pq < R * R; pq += 256) {
+  for (int pq = tid; pq < R * R; pq += VNL_CORR_THREADS) {
     const int i = pq / R, j = pq - i * R;
     // (every lane starts at a column of its own: rows are B floats apart, so equal columns would share one LDS bank)
-    float d = 0.f;
-    int col = tid % B;
-#pragma unroll 8  // eight independent LDS read pairs in flight (one per trip was 35 us for T = 20, B = 128)
-    for (int k = 0; k < B; k++) {
-      d += xs[(size_t)i * B + col] * xs[(size_t)j * B + col];
-      col = col + 1 == B ? 0 : col + 1;
+    // four independent partial sums, the column computed from k (no loop-carried address): the loop was one LDS latency
+    // per step (35 us for T = 20, B = 128) while its chain ran through `d` and the wrapped column
+    const int col0 = tid % B;
+    const float* xi = xs + (size_t)i * B;
+    const float* xj = xs + (size_t)j * B;
+    float d4[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= B; k += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int col = col0 + k + u;
+        col = col >= B ? col - B : col;
+        d4[u] += xi[col] * xj[col];
+      }
     }
+    for (; k < B; k++) {
+      int col = col0 + k;
+      col = col >= B ? col - B : col;
+      d4[0] += xi[col] * xj[col];
+    }
+    const float d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
     const float c = d / (nrm[i] * nrm[j]);
     acc += c != c ? c : fminf(fmaxf(c, -1.f), 1.f);
   }
   red[tid] = acc;
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
+  for (int k = VNL_CORR_THREADS / 2; k > 0; k >>= 1) {
     if (tid < k) red[tid] += red[tid + k];
     __syncthreads();
   }
@@ -994,7 +1015,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     // metrics[8] = prediction_corr (a metric only), in the same slack; 0 when the 2T rows do not fit in LDS
     const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
     if (lds <= 60 * 1024)
-      hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(256), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
+      hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(VNL_CORR_THREADS), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
                          u->T, u->B, metrics + 8);
     else
       PCHK(hipMemsetAsync(metrics + 8, 0, sizeof(float), st));
