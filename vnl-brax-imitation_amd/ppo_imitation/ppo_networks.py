@@ -117,8 +117,8 @@ def _rand_action(n: int, key: Optional[torch.Generator], device) -> torch.Tensor
     """One U(-1, 1) pre-tanh action shared by the whole batch (ppo_networks.py:67-69), drawn on the device the
     generator lives on (a host draw + copy would synchronise the rollout loop every step)."""
     if key is not None and key.device.type != torch.device(device).type:
-        return (torch.rand((n,), generator=key) * 2 - 1).to(device)
-    return torch.rand((n,), generator=key, device=device) * 2 - 1
+        return torch.empty((n,), dtype=torch.float32).uniform_(-1.0, 1.0, generator=key).to(device)
+    return torch.empty((n,), dtype=torch.float32, device=device).uniform_(-1.0, 1.0, generator=key)  # one launch, not three
 
 
 def make_inference_fn(ppo_networks: PPOImitationNetworks):
