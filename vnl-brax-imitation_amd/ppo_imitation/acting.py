@@ -70,7 +70,9 @@ def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int
     T, info, dev = unroll_length, env_state.info, env_state.obs.device
     B = st.obs.shape[0]
     new = lambda *shape, like: torch.empty((T, *shape), dtype=like.dtype, device=dev)  # noqa: E731
-    obs_log, nobs_log = new(*st.obs.shape, like=st.obs), new(*st.obs.shape, like=st.obs)
+    # Transition.observation[t + 1] IS next_observation[t] (the auto-reset wrapper's obs is what the next step sees), so only
+    # the first row is copied; the policy reads the live observation buffer
+    obs0, nobs_log = st.obs.clone(), new(*st.obs.shape, like=st.obs)
     rew_log, disc_log = new(B, like=st.reward), new(B, like=st.reward)
     sx_log = {x: new(*info[x].shape, like=info[x]) for x in extra_fields}
     prev_done = st.done.clone()
@@ -100,8 +102,7 @@ def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int
     px_log: Optional[dict] = None
     act_log = None
     for t in range(T):
-        obs_log[t].copy_(st.obs)
-        actions, pex = policy(info["traj"], obs_log[t], key)
+        actions, pex = policy(info["traj"], st.obs, key)
         base.step(st, actions)
         if px_log is None:
             act_log = new(*actions.shape, like=actions)
@@ -121,6 +122,7 @@ def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int
         d.log_truncation = ptr(sx_log["truncation"][t]) if "truncation" in sx_log else C.c_void_p(0)
         _lib.check(base._L, base._L.vnl_rollout_post(C.byref(d), B, stream))
         _generate_unroll_fused.hold = keep  # the launch is asynchronous: keep this step's sources alive
+    obs_log = torch.cat((obs0[None], nobs_log[:-1]), dim=0)
     data = Transition(observation=obs_log, action=act_log, reward=rew_log, discount=disc_log, next_observation=nobs_log,
                       extras={"policy_extras": px_log, "state_extras": sx_log})
     return st, data
