@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=8)
     ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--first", type=int, default=100, help="first seed")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.envs.rodent import RodentTracking
 
@@ -29,7 +30,7 @@ def main():
     env1 = RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", **{**H.env_kwargs(), "n_frames": 1})
     o64, o32 = H.make_oracle(env, "f64"), H.make_oracle(env, "f32")
     o64_1, o32_1 = H.make_oracle(env1, "f64"), H.make_oracle(env1, "f32")
-    for seed in range(100, 100 + a.seeds):
+    for seed in range(a.first, a.first + a.seeds):
         rng = np.random.default_rng(seed)
         sf = rng.integers(0, 235, B).astype(np.int32)
         noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
@@ -41,8 +42,8 @@ def main():
         for k, (e1, d1, r1) in enumerate(P.resync_substeps(env1, o64_1, o32_1, sf, noise, act, nsub=3)):
             viol = sum(len(v) for v in P.bound_violations(e1, d1).values())
             r = r1.reshape(len(r1), -1, r1.shape[-1])[:, 0]
-            kinks = int(((r[:, 3] > 0) & (r[:, 4] <= P.KINK_MARGIN_MAX)).sum())
-            sub.append({"substep": k, "qvel max": float(e1["qvel"].max()), "violations": int(viol), "kink envs (natural-oracle reference)": kinks})
+            sub.append({"substep": k, "qvel max": float(e1["qvel"].max()), "violations": int(viol),
+                        "non-tie solves (natural-oracle reference)": int(P.non_tie(r).sum())})
             assert viol == 0
         print(json.dumps({"seed": seed, "envs": B, "control step": {k: [float(np.median(v)), float(v.max())] for k, v in err.items()
                                                                      if k in ("qpos", "qvel", "qacc_warmstart", "xpos")},
