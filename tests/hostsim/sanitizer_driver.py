@@ -1,0 +1,34 @@
+"""Run by tests/test_sanitizers.py under LD_PRELOAD=libasan.so:libubsan.so: reset + a few control steps of the rodent, the
+humanoid and the ant through the host build of the kernels compiled with -fsanitize=address,undefined (argv[1])."""
+import sys, ctypes
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+import helpers as H
+from vnl_brax_imitation_amd import _lib
+from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+lib = _lib.load_library(sys.argv[1], env_only=True)
+kw = H.env_kwargs()
+env = RodentTracking(H.reference_clip(), num_envs=3, device="cpu", _library=lib, **kw)
+rng = np.random.default_rng(0)
+st = env.reset(5)
+for _ in range(3):
+    st = env.step(st, torch.from_numpy(np.clip(0.3 * rng.standard_normal((3, 30)), -1, 1).astype(np.float32)))
+print("rodent ok", float(st.reward.sum()), bool(torch.isfinite(st.obs).all()))
+# humanoid + ant models through the same library
+from vnl_brax_imitation_amd.model import mjcf
+from vnl_brax_imitation_amd.envs.humanoid import HumanoidTracking
+from vnl_brax_imitation_amd.envs.ant import AntTracking
+hm = mjcf.CompiledModel.load(os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "humanoid.npz"))
+h = HumanoidTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=hm, num_envs=2, device="cpu", _library=lib)
+s = h.reset(1)
+for _ in range(2):
+    s = h.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 21)), -1, 1).astype(np.float32)))
+print("humanoid ok", bool(torch.isfinite(s.obs).all()))
+am = mjcf.CompiledModel.load(os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "ant.npz"))
+a = AntTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=am, num_envs=2, device="cpu", _library=lib)
+s = a.reset()
+for _ in range(2):
+    s = a.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 8)), -1, 1).astype(np.float32)))
+print("ant ok", bool(torch.isfinite(s.obs).all()))
