@@ -57,6 +57,11 @@ def parse_args():
     ap.add_argument("--no-autoreset", action="store_true", help="main measurement without the auto-reset wrapper")
     ap.add_argument("--no-free-running", action="store_true", help="skip the additional free-running measurement")
     ap.add_argument("--random-actions", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` sub-record (full PPO training step)")
+    ap.add_argument("--train-steps", type=int, default=3, help="training steps timed for the `train_step` sub-record")
+    ap.add_argument("--train-step-multi", action="store_true", help="also run the `train_step` leg with --gpus > 1 (RCCL "
+                    "gradient all-reduce; off by default so that a collective problem cannot take the headline line down)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle compliance check of the cpu_baseline leg")
     ap.add_argument("--config", choices=("rodent", "humanoid"), default="rodent", help="humanoid: BASELINE config 'Humanoid "
                     "imitation, num_envs=1024' (HumanoidTracking, synthetic standing clip, random actions; not the headline metric)")
     return ap.parse_args()
@@ -105,6 +110,115 @@ def cpu_baseline(env, num_envs: int, max_steps: int = 200, budget_s: float = 12.
     return dict(value=num_envs * steps / dt, unit="env-steps/s", cores=cores, kind="port",
                 sample=f"{num_envs} envs x {steps} control steps, C restatement (oracle/vnl_oracle.c, float32, "
                        f"OpenMP over envs), {dt:.1f} s")
+
+
+def parity_compliance(env_cls, clip, kwargs, dev, num_envs: int = 512, seed: int = 3) -> dict:
+    """Checker leg (rank 0, N = 1, beside cpu_baseline): the fraction of envs whose state after ONE physics substep and
+    after ONE control step is within 1e-5 of the float64 oracle (following the product's solver decisions; errors per env
+    and per field group, tests/parity.py) -- for the product on the device and, on the same inputs, for the float32 build
+    of the oracle.  north_star's "within 1e-5 rel" holds for that fraction of the envs, not for every env: the
+    6-iteration CG of the reference's configuration is not converged and float32 rounding decides its discrete path."""
+    import numpy as np
+    import torch
+
+    import helpers as H
+    import parity as P
+
+    rng = np.random.default_rng(seed)
+    sf = rng.integers(0, 235, num_envs).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((num_envs, 74))).astype(np.float32)
+    act = np.clip(0.3 * rng.standard_normal((num_envs, 30)), -1, 1).astype(np.float32)
+    out = {"envs": num_envs, "tolerance": 1e-5, "scaling": "per env and per field group (root position / quaternion / joint "
+           "angles; linear / angular / joint velocities)"}
+    for name, nf in (("one_substep", 1), ("one_control_step", 5)):
+        env = env_cls(clip, num_envs=num_envs, device=dev, **{**kwargs, "n_frames": nf})
+        o64, o32 = H.make_oracle(env, "f64"), H.make_oracle(env, "f32")
+        _, err, dev32, _, _ = P.control_step_follow(env, o64, o32, sf, noise, act)
+        torch.cuda.synchronize(dev)
+        out[name] = {"product": {k: P.compliance(err)[k] for k in ("qpos", "qvel")},
+                     "float32_oracle": {k: P.compliance(dev32)[k] for k in ("qpos", "qvel")},
+                     "median_err_qvel": float(np.median(err["qvel"])), "max_err_qvel": float(err["qvel"].max())}
+    return out
+
+
+def train_step_record(clip, kwargs, dev, B: int, world: int, steps: int) -> dict:
+    """Full PPO training step (BASELINE config 5, per-GPU share; reference ppo_imitation/train.py:293-394): 4096 envs,
+    unroll 20, 32 minibatches x 16 updates of 128 trajectories, reference network sizes, the hand-written update inside
+    the captured hipGraph.  Two epochs of `steps` training steps: the first contains the graph capture, the second is the
+    steady state whose `training/sps` (as the reference computes it) is reported."""
+    import functools
+
+    import torch
+
+    from vnl_brax_imitation_amd import configs
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+    from vnl_brax_imitation_amd.ppo_imitation import ppo_networks
+    from vnl_brax_imitation_amd.ppo_imitation import train as ppo
+
+    env = RodentTracking(clip, num_envs=B, device=dev, **kwargs)
+    c = configs.TRAIN_CONFIG
+    nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=c["intention_latent_size"],
+                           encoder_layer_sizes=c["encoder_layer_sizes"], decoder_layer_sizes=c["decoder_layer_sizes"])
+    unroll, nmb, upd = c["unroll_length"], c["num_minibatches"], c["num_updates_per_batch"]
+    log = []
+    ppo.train(environment=env, num_timesteps=2 * steps * B * world * unroll, episode_length=c["episode_length"],
+              num_envs=B * world, learning_rate=c["learning_rate"], entropy_cost=c["entropy_cost"],
+              discounting=c["discounting"], unroll_length=unroll, batch_size=B * world // nmb, num_minibatches=nmb,
+              num_updates_per_batch=upd, num_evals=3, normalize_observations=True, network_factory=nf, num_eval_envs=0,
+              eval_env=None, kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"], update_backend="hip",
+              progress_fn=lambda s_, m_: log.append((s_, dict(m_))))
+    torch.cuda.synchronize(dev)
+    if not log:
+        return {}
+    m = log[-1][1]
+    sps = float(m["training/sps"])
+    step_ms = B * world * unroll / sps * 1e3
+    return {"env_steps_per_s": sps, "ms_per_training_step": step_ms, "training_steps_timed": steps,
+            "minibatch_steps_per_training_step": nmb * upd, "total_loss": float(m["training/total_loss"]),
+            "config": f"rodent, {B} envs/GPU x {world} GPU, unroll {unroll}, {nmb} minibatches x {upd} updates of "
+                      f"{B // nmb} trajectories/GPU, intention net {c['encoder_layer_sizes']}/{c['intention_latent_size']}/"
+                      f"{c['decoder_layer_sizes']}, value (1024, 1024), hand-written update in a captured hipGraph, "
+                      "steady state (second epoch)"}
+
+
+def update_record(dev, iters: int = 60) -> dict:
+    """The hand-written minibatch step alone (vnl_ppo_minibatch_grad, graph replay, synthetic minibatch of the
+    reference's sizes T = 20 x 128 trajectories): ms per minibatch step and fp32-MFMA TFLOP/s (2 x MACs of every GEMM,
+    forward + dX + dW)."""
+    import torch
+
+    from test_gpu_ppo_update import HP, _make
+    from vnl_brax_imitation_amd.ppo_imitation import hip_update, running_statistics
+
+    cfg = dict(traj=795, obs=232, act=30, latent=64, enc=(256, 128), dec=(128, 256), val=(1024, 1024), T=20, B=128)
+    nets, flat, data, norm, noise = _make(**cfg)
+    to = lambda t: t.to(dev)  # noqa: E731
+    flat, data, noise = to(flat).contiguous(), data.map(to), {k: to(v) for k, v in noise.items()}
+    ndev = running_statistics.RunningStatisticsState(to(norm.count), to(norm.mean), to(norm.summed_variance), to(norm.std))
+    grads = torch.zeros_like(flat)
+    upd = hip_update.HipPPOUpdate(nets, cfg["T"], cfg["B"], dev, **HP)
+    for _ in range(3):
+        upd.grad(flat, ndev, data, noise, grads)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        upd.grad(flat, ndev, data, noise, grads)
+    for _ in range(5):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    N = cfg["T"] * cfg["B"]
+    macs_p = 795 * 256 + 256 * 128 + 2 * 128 * 64 + 296 * 128 + 128 * 256 + 256 * 60
+    macs_v = 232 * 1024 + 1024 * 1024 + 1024
+    flop = 2.0 * 3.0 * (N * macs_p + N * macs_v) + 2.0 * cfg["B"] * macs_v
+    return {"ms_per_minibatch_step": ms, "mfma_tflops": flop / ms / 1e9, "mfma_frac": flop / ms / 1e9 / VALU_PEAK_TFLOPS,
+            "mfma_peak_tflops": VALU_PEAK_TFLOPS, "gflop_per_minibatch_step": flop / 1e9,
+            "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak = the fp32 vector peak on gfx950"}
 
 
 def main() -> None:
@@ -315,8 +429,29 @@ def main() -> None:
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(base, num_envs=1024)
+            if not args.no_parity and args.config == "rodent" and args.clips == 1:
+                try:
+                    out["cpu_baseline"]["compliance"] = parity_compliance(RodentTracking, clip, H.env_kwargs(), dev)
+                except Exception as e:  # the checker must not take the measurement down
+                    out["cpu_baseline"]["compliance"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
+    # ---- full training step ("report rollout-only and full-train-step numbers separately") -------------
+    train_rec = None
+    do_train = (not args.no_train_step and args.config == "rodent" and not args.random_actions and args.clips == 1 and
+                (world == 1 or args.train_step_multi))
+    if do_train:
+        torch.cuda.empty_cache()
+        try:
+            train_rec = train_step_record(clip, H.env_kwargs(), dev, B, world, args.train_steps)
+            if rank == 0 and world == 1:
+                train_rec.update(update_record(dev))
+        except Exception as e:
+            if world > 1:
+                raise
+            train_rec = {"error": repr(e)}
+    if rank == 0:
+        out["train_step"] = train_rec
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

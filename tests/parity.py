@@ -79,9 +79,43 @@ def oracle_state_from(env, oracle, state) -> dict:
 
 
 def per_env_scaled(a, ref) -> np.ndarray:
-    """max_k |a - ref| per env, divided by the scale of the whole reference array."""
+    """max_k |a - ref| per env, divided by the scale of the whole reference array (used for the glue outputs, whose
+    entries share one unit; the physics state goes through per_env_grouped)."""
     a, ref = np.asarray(a, np.float64).reshape(len(ref), -1), np.asarray(ref, np.float64).reshape(len(ref), -1)
     return np.max(np.abs(a - ref), axis=1) / max(float(np.max(np.abs(ref))), 1e-30)
+
+
+# Field groups of the physics state (free-joint root first, as in every model of the reference): quantities of one unit
+# and one physical meaning are scaled together, PER ENV -- not by the largest entry of the whole batch (a batch-wide qvel
+# scale of 22.7 rad/s made "1e-5" mean 5e-4 of a median entry; VERDICT r02 weak 3).
+GROUPS = {
+    "qpos": (("root position", slice(0, 3)), ("root quaternion", slice(3, 7)), ("joint angles", slice(7, None))),
+    "qvel": (("linear velocity", slice(0, 3)), ("angular velocity", slice(3, 6)), ("joint velocities", slice(6, None))),
+    "qacc_warmstart": (("linear acceleration", slice(0, 3)), ("angular acceleration", slice(3, 6)),
+                       ("joint accelerations", slice(6, None))),
+}
+
+
+def group_scales(ref, key: str) -> list:
+    """[(name, slice, scale (B,))]: the scale of group g in env e is max(largest |ref| of the group in that env, the batch
+    MEDIAN of that quantity): an env at rest in some group is measured against a typical env, never against the batch's
+    worst one."""
+    ref = np.asarray(ref, np.float64).reshape(len(ref), -1)
+    out = []
+    for name, sl in GROUPS.get(key, (("all", slice(0, None)),)):
+        own = np.max(np.abs(ref[:, sl]), axis=1) if ref[:, sl].shape[1] else np.zeros(len(ref))
+        out.append((name, sl, np.maximum(np.maximum(own, float(np.median(own))), 1e-30)))
+    return out
+
+
+def per_env_grouped(a, ref, key: str) -> np.ndarray:
+    """max over the field groups of `key` of (max_k in group |a - ref|) / (scale of that group in that env)."""
+    a, ref = np.asarray(a, np.float64).reshape(len(ref), -1), np.asarray(ref, np.float64).reshape(len(ref), -1)
+    err = np.zeros(len(ref))
+    for _, sl, scale in group_scales(ref, key):
+        if ref[:, sl].shape[1]:
+            err = np.maximum(err, np.max(np.abs(a[:, sl] - ref[:, sl]), axis=1) / scale)
+    return err
 
 
 STATE_KEYS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "qfrc_actuator")
@@ -90,9 +124,14 @@ STATE_KEYS = ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "qfrc_actuator")
 def state_errors(state, ost) -> dict:
     B = len(ost["qpos"])
     ps = state.pipeline_state
-    out = {k: per_env_scaled(to_np(getattr(ps, k)).reshape(B, -1), ost[k]) for k in STATE_KEYS}
-    out["com1"] = per_env_scaled(to_np(ps.subtree_com_root), ost["com1"])
+    out = {k: per_env_grouped(to_np(getattr(ps, k)).reshape(B, -1), ost[k], k) for k in STATE_KEYS}
+    out["com1"] = per_env_grouped(to_np(ps.subtree_com_root), ost["com1"], "com1")
     return out
+
+
+def compliance(err: dict, tol: float = 1e-5) -> dict:
+    """{field: fraction of the envs whose error is within `tol` of the env's own group scales}"""
+    return {k: float(np.mean(v <= tol)) for k, v in err.items()}
 
 
 def _as_f32_state(ost: dict) -> dict:
@@ -156,8 +195,8 @@ def follow_compare(env, o64, o32, state_before_fn, step_fn, action, n_frames):
                 t32[k] = (t32[k] * (1 + np.float32(2.0 ** -23) * rng.integers(-1, 2, t32[k].shape).astype(np.float32))).astype(np.float32)
         t32, _, _ = o32.env_step_follow(t32, action.astype(np.float32), ptr)
         for k in STATE_KEYS:
-            dev[k] = np.maximum(dev[k], per_env_scaled(t32[k].astype(np.float64), s64[k]))
-        dev["com1"] = np.maximum(dev["com1"], per_env_scaled(t32["com1"].astype(np.float64), s64["com1"]))
+            dev[k] = np.maximum(dev[k], per_env_grouped(t32[k].astype(np.float64), s64[k], k))
+        dev["com1"] = np.maximum(dev["com1"], per_env_grouped(t32["com1"].astype(np.float64), s64["com1"], "com1"))
     if n_frames == 1:
         # Envs in whose solve a followed decision was NOT a tie for the oracle (non_tie): a row on the other side of its
         # switching point at one of the product's trial step lengths (a kink), or a bracket / exit / warm-start decision
@@ -182,7 +221,7 @@ def follow_compare(env, o64, o32, state_before_fn, step_fn, action, n_frames):
                         t32[k] = (t32[k] * (1 + np.float32(2.0 ** -23) * rng.integers(-1, 2, t32[k].shape).astype(np.float32))).astype(np.float32)
                 t32 = o32.env_step(t32, action.astype(np.float32))
                 for k in d_nat:
-                    d_nat[k] = np.maximum(d_nat[k], per_env_scaled(t32[k].astype(np.float64), n64[k]))
+                    d_nat[k] = np.maximum(d_nat[k], per_env_grouped(t32[k].astype(np.float64), n64[k], k))
             for k in err:
                 err[k][kink], dev[k][kink] = e_nat[k][kink], d_nat[k][kink]
             LAST["kink_envs"] = kink
@@ -209,6 +248,21 @@ def assert_no_less_accurate_than_f32_oracle(err: dict, dev: dict, keep=None) -> 
 def bound_violations(err: dict, dev: dict, tol=TOL, k=K_SENS) -> dict:
     """{field: indices of envs with err > max(tol, k * dev)}"""
     return {f: np.where(err[f] > np.maximum(tol, k * dev[f]))[0] for f in err}
+
+
+ALPHA_GAP_MAX = 1e-2  # largest relative distance between a trial step length of the oracle and the followed side's
+
+
+def faithful(r: np.ndarray) -> np.ndarray:
+    """rows of a follow report (..., 12) -> bool: the oracle's REPLAY of the other side's decisions was faithful -- every
+    trial step length of its line searches was (within ALPHA_GAP_MAX) the other side's, and the same number of rows was
+    active at each.  Only then do the recorded bracket decisions refer to the oracle's own trial points, and only then is a
+    followed decision that is not a tie evidence against the product.  (With one differing trial point the two searches
+    run on different brackets from there on; replaying decisions taken on other points leaves the oracle off its
+    minimiser although both searches, left alone, end at the same one: those solves are re-checked against the NATURAL
+    oracle instead, see follow_compare.  Recorded data: of 32,768 solves in the four 4096-env dumps behind
+    tests/golden/parity_cases.npz, every faithful replay had all three tie measures <= 0.07.)"""
+    return (r[..., 3] == 0) & (r[..., 8] <= ALPHA_GAP_MAX)
 
 
 def non_tie(r: np.ndarray) -> np.ndarray:
@@ -269,11 +323,48 @@ def check_control_step(err: dict, dev: dict, rep: np.ndarray, verbose: bool = Tr
     return int(flipped.sum())
 
 
+def natural_check(state, o64, o32, action, q50=1.5, q90=3.0, fields=("qpos", "qvel", "qacc_warmstart")) -> dict:
+    """Decision-INDEPENDENT companion of a follow comparison: the product's post-step state against the
+    NATURAL float64 oracle (its own decisions) started from the pre-step state of the last follow_compare, with the
+    natural float32 oracle as the yardstick.  A wrong line-search or active-set decision of the product would be replayed
+    by a following oracle, but not by this one.  Per-env agreement is not expected (different discrete paths in the
+    ill-conditioned envs); the DISTRIBUTION must be no worse than the float32 oracle's: median within `q50` x and 90 %
+    quantile within `q90` x the float32 oracle's (+ TOL)."""
+    before = LAST["before"]
+    n64 = o64.env_step({k: v.copy() for k, v in before.items()}, np.asarray(action, np.float64))
+    n32 = o32.env_step(_as_f32_state({k: v.copy() for k, v in before.items()}), np.asarray(action, np.float32))
+    e = state_errors(state, n64)
+    out = {}
+    for f in fields:
+        d = per_env_grouped(n32[f].astype(np.float64), n64[f], f)
+        out[f] = dict(median=float(np.median(e[f])), q90=float(np.quantile(e[f], 0.9)), median_f32=float(np.median(d)),
+                      q90_f32=float(np.quantile(d, 0.9)))
+        assert out[f]["median"] <= q50 * out[f]["median_f32"] + TOL, (f, out[f])
+        assert out[f]["q90"] <= q90 * out[f]["q90_f32"] + TOL, (f, out[f])
+    return out
+
+
+def flip_causes(rep: np.ndarray) -> dict:
+    """For the envs `drifted` flags: what the evidence is -- a constraint row present on one side only (report [6]), an
+    active-set mismatch at a trial step (report [3]) or a line-search / exit / warm-start decision off its tie."""
+    fl = np.where(drifted(rep))[0]
+    rows = rep[fl][..., 6].sum(axis=-1) > 0
+    kinks = rep[fl][..., 3].sum(axis=-1) > 0
+    return dict(envs=fl, row_presence=rows, active_set=kinks & ~rows, other=~rows & ~kinks)
+
+
 def assert_legitimate(rep: np.ndarray) -> dict:
     """Single-substep comparison: decisions that are not ties for the oracle must be rare (measured over 100 seeds x 3
     substeps x 4096 envs: 0-2 per 4096 solves) -- their envs are checked against the natural oracle by follow_compare --
     and a constraint row present on one side only must be within rounding of its threshold."""
     s = legitimacy_summary(rep)
+    # hard: wherever the replay was faithful (same trial points, same active sets), every followed decision is a tie
+    r = rep.reshape(-1, rep.shape[-1])
+    f = faithful(r)
+    s["faithful_solves"] = int(f.sum())
+    s["faithful_worst_tie"] = float(np.max(np.maximum.reduce([r[f, 0], r[f, 1], r[f, 2]]))) if f.any() else 0.0
+    assert s["faithful_worst_tie"] <= 1.0, s
+    # the rest: rare, and held to the same bound against the natural oracle (follow_compare)
     assert s["non_tie_solves"] <= max(2, s["solves"] // 500), s
     assert s["row_depth"] <= ROW_DEPTH_MAX, s
     return s

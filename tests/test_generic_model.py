@@ -91,6 +91,12 @@ def test_ant_model_on_gpu_matches_oracle():
     for k, tol in (("qpos", 1e-6), ("xpos", 2e-6)):
         assert H.scaled_err(getattr(ps, k).reshape(B, -1).cpu().numpy(), ost[k]) < tol, k
     assert H.scaled_err(st.obs.cpu().numpy(), ost["obs"]) < 1e-6
+    # decision-independent: the reset solve against the NATURAL oracle.  qacc passes through the 6-iteration constraint
+    # solve and an env at a contact-activation threshold is sensitive to float32 rounding (the float32 host build shows
+    # the same), so per-env quantiles rather than the maximum
+    qa = ps.qacc_warmstart.cpu().numpy()
+    per_env_a = np.array([H.scaled_err(qa[i], ost["qacc_warmstart"][i]) for i in range(B)])
+    assert np.median(per_env_a) < 2e-6 and np.quantile(per_env_a, 0.9) < 2e-5, (np.median(per_env_a), per_env_a.max())
     # one control step against the oracles made to follow the product's solver decisions (tests/parity.py): every env
     # within max(1e-5 of the array's scale, 50 x the float32 oracle's own deviation on that env) -- no quantiles
     import parity as P
@@ -103,4 +109,13 @@ def test_ant_model_on_gpu_matches_oracle():
     # float32 tie far more often than for the rodent (9 of 128 envs measured on the device, 1 of 32 in the host build):
     # those envs must still show the flipped decision and stay within 1000 x their sensitivity (check_control_step)
     P.check_control_step(err, dev, rep, max_flipped=B // 8)
+    # every flipped env beyond the rodent's allowance (1 %) must be explained by that mechanism: a contact row present on
+    # one side only (report [6]) -- not by a line-search or exit decision off its tie
+    causes = P.flip_causes(rep)
+    print(f"   flipped envs {len(causes['envs'])}: contact-row presence {int(causes['row_presence'].sum())}, active set at a trial "
+          f"step {int(causes['active_set'].sum())}, other {int(causes['other'].sum())}")
+    assert int((~causes["row_presence"]).sum()) <= max(2, B // 50), causes
+    # and decision-independent: the product against the NATURAL float64 oracle over the control step, no worse than the
+    # natural float32 oracle in distribution (a wrong decision of the product would be replayed by a following oracle)
+    print("   vs the natural oracle:", P.natural_check(st, o, o32, act))
     assert np.array_equal(st.done.cpu().numpy(), ost["done"].astype(np.float32))

@@ -53,4 +53,4 @@ def test_spilling_build_matches_oracle_and_product_build():
     same = {k: bool(np.array_equal(outs[0][k], outs[1][k])) for k in outs[0]}
     worst = {k: float(P.per_env_scaled(outs[0][k], outs[1][k].astype(np.float64)).max()) for k in outs[0]}
     print("[spill vs product build, 3 steps] bitwise equal:", same, "worst scaled difference:", worst)
-    assert all(same.values()) or max(worst.values()) < 1e-4, (same, worst)
+    assert all(same.values()), (same, worst)  # bit for bit, as DESIGN section 2 item 3 states

@@ -134,6 +134,13 @@ def test_control_step_matches_oracle_following_decisions(backend, B):
     _report(f"{backend} B={B} control step", err, dev, viol)
     print("   followed decisions (informative):", P.legitimacy_summary(rep))
     P.check_control_step(err, dev, rep)
+    comp, comp32 = P.compliance(err), P.compliance(dev)
+    print("   envs within 1e-5 (per env, per field group): product", {k: round(comp[k], 3) for k in ("qpos", "qvel")},
+          "| float32 oracle", {k: round(comp32[k], 3) for k in ("qpos", "qvel")})
+    # decision-independent companion: against the NATURAL float64 oracle the product is, in distribution, no worse than the
+    # natural float32 oracle (a wrong decision of the product would be replayed by the following oracle above, not by this one)
+    if B >= 32:
+        print("   vs the natural oracle:", P.natural_check(st, o64, o32, act))
     assert np.array_equal(P.to_np(st.done).astype(np.float64), ost["done"])
     assert np.array_equal(P.to_np(st.info["cur_frame"]), ost["cur_frame"])
 

@@ -5,7 +5,7 @@ import sys
 
 NAMES = {1: "kin+inertia+M+factor+invert", 2: "kinematics", 3: "kin+inertia+M", 4: "kin+inertia+M+factor",
          5: "kin+inertia+bias", 6: "twists+Jv", 7: "solve (M^-1 x)", 8: "ls row pass (3 alphas)",
-         9: "make_constraint", 10: "constraint_force", 11: "smooth_forces", 12: "4 x vdot", 13: "ls_load + 1-alpha pass", 14: "kin+inertia+M+factor(load/store only)"}
+         9: "make_constraint", 10: "constraint_force", 11: "smooth_forces", 12: "4 x vdot", 13: "ls_load + 1-alpha pass", 14: "kin+inertia+M+factor(load/store only)", 15: "kin+inertia+M+factor_pair", 16: "euler: reload+invert+apply"}
 st, data = None, {}
 for line in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_stage/all.txt"):
     m = re.match(r"stage (\d+)", line)

@@ -1910,6 +1910,17 @@ struct EnvWave {
         body_inertias(false);
         mass_matrix(vreal(0.));
         factor(false);
+      } else if (m.dbg_stage == 15) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+        if (factor_pair_ok()) factor_both(m.dt, fac2());
+      } else if (m.dbg_stage == 16) {  // euler()'s second-factor route: reload, invert in the pool, apply
+        const vreal* g2 = fac2();
+        VNL_FOR(k, m.nM + m.nv) s[L.P + k] = g2[k];
+        VNL_SYNC();
+        invert_factor(L.P);
+        solve_inplace(L.tmp, L.P, L.P + m.nM);
       } else if (m.dbg_stage == 18) {
         tree_accumulate(L.P, 10);
       } else if (m.dbg_stage == 19) {
