@@ -67,6 +67,31 @@ def hostsim_library(real: str = "float") -> C.CDLL:
     return _lib.load_library(build_hostsim(real), env_only=True)
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def backend(library, dtype=None):
+    """Envs constructed inside bind to `library` (the host build of the product source, or a regression build) instead
+    of csrc/libvnl.so: the test seam of envs/rodent.py (`_TEST_BACKEND`), kept out of the public constructors."""
+    import torch
+
+    from vnl_brax_imitation_amd.envs import rodent as _rodent
+
+    prev = _rodent._TEST_BACKEND
+    _rodent._TEST_BACKEND = None if library is None else (library, dtype or torch.float32)
+    try:
+        yield
+    finally:
+        _rodent._TEST_BACKEND = prev
+
+
+def hostsim_backend(real: str = "float"):
+    import torch
+
+    return backend(hostsim_library(real), torch.float64 if real == "double" else torch.float32)
+
+
 def hostsim_env(num_envs: int, real: str = "float", **over):
     """RodentTracking bound to the host simulation (CPU tensors)."""
     import torch
@@ -76,8 +101,8 @@ def hostsim_env(num_envs: int, real: str = "float", **over):
     kw = env_kwargs()
     kw.update(over)
     clip = kw.pop("reference_clip", None) or reference_clip()
-    return RodentTracking(clip, num_envs=num_envs, device="cpu", _library=hostsim_library(real),
-                          _dtype=torch.float64 if real == "double" else torch.float32, **kw)
+    with hostsim_backend(real):
+        return RodentTracking(clip, num_envs=num_envs, device="cpu", **kw)
 
 
 def make_oracle(env, precision="f64"):

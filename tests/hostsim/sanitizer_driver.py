@@ -10,7 +10,9 @@ from vnl_brax_imitation_amd import _lib
 from vnl_brax_imitation_amd.envs.rodent import RodentTracking
 lib = _lib.load_library(sys.argv[1], env_only=True)
 kw = H.env_kwargs()
-env = RodentTracking(H.reference_clip(), num_envs=3, device="cpu", _library=lib, **kw)
+ctx = H.backend(lib)
+ctx.__enter__()  # every env below binds to the sanitizer build of the host library
+env = RodentTracking(H.reference_clip(), num_envs=3, device="cpu", **kw)
 rng = np.random.default_rng(0)
 st = env.reset(5)
 for _ in range(3):
@@ -21,13 +23,13 @@ from vnl_brax_imitation_amd.model import mjcf
 from vnl_brax_imitation_amd.envs.humanoid import HumanoidTracking
 from vnl_brax_imitation_amd.envs.ant import AntTracking
 hm = mjcf.CompiledModel.load(os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "humanoid.npz"))
-h = HumanoidTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=hm, num_envs=2, device="cpu", _library=lib)
+h = HumanoidTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=hm, num_envs=2, device="cpu")
 s = h.reset(1)
 for _ in range(2):
     s = h.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 21)), -1, 1).astype(np.float32)))
 print("humanoid ok", bool(torch.isfinite(s.obs).all()))
 am = mjcf.CompiledModel.load(os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "ant.npz"))
-a = AntTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=am, num_envs=2, device="cpu", _library=lib)
+a = AntTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=am, num_envs=2, device="cpu")
 s = a.reset()
 for _ in range(2):
     s = a.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 8)), -1, 1).astype(np.float32)))

@@ -50,7 +50,8 @@ def test_bad_blob_and_missing_device_are_reported():
         with pytest.raises(_lib.VnlError, match="no CPU fallback|HIP device"):
             RodentTracking(H.reference_clip(), num_envs=2, device="cpu", **H.env_kwargs())
         with pytest.raises(_lib.VnlError, match="no HIP device|hipSetDevice|HIP"):
-            RodentTracking(H.reference_clip(), num_envs=2, device="cpu", _library=lib, **H.env_kwargs())
+            with H.backend(lib):
+                RodentTracking(H.reference_clip(), num_envs=2, device="cpu", **H.env_kwargs())
     lib.vnl_model_destroy(h)
 
 

@@ -12,7 +12,8 @@ from vnl_brax_imitation_amd.preprocessing import mjx_preprocess as pp
 def _check(device, lib=None, frames=250, chunk=4096):
     m, q = H.model(), H.golden_qpos()[:frames]
     ref = pp.process_qpos(m, q)
-    qn, xpos, xquat, com = pp.forward_kinematics_device(m, q, device=device, chunk=chunk, _library=lib)
+    with H.backend(lib):
+        qn, xpos, xquat, com = pp.forward_kinematics_device(m, q, device=device, chunk=chunk)
     scale = np.abs(ref.body_positions).max()
     assert np.abs(xpos - ref.body_positions).max() / scale < 2e-6
     assert np.abs(com - ref.center_of_mass).max() / scale < 2e-6

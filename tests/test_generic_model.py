@@ -42,12 +42,14 @@ def _ant_env(B, real, device="cpu"):
     qpos[:, 7:] = base + 0.15 * np.sin(2 * np.pi * 1.5 * t + np.arange(8))
     clip = P.process_qpos(m, qpos, max_qvel=20.0, dt=0.02)
     names = m.names
-    env = RodentTracking(
-        clip, end_eff_names=["aux_1", "aux_2", "aux_3", "aux_4"], appendage_names=["aux_1", "aux_2", "aux_3", "aux_4", "torso"],
-        walker_body_names=[n for n in names["body"] if n != "world"], joint_names=names["joint"][1:],
-        center_of_mass="torso", model=m, clip_length=T, sub_clip_length=10, ref_traj_length=5, healthy_z_range=(0.2, 1.0),
-        num_envs=B, device=device, _library=H.hostsim_library(real) if device == "cpu" else None,
-        _dtype=torch.float64 if real == "double" else torch.float32)
+    import contextlib
+
+    with (H.hostsim_backend(real) if device == "cpu" else contextlib.nullcontext()):
+        env = RodentTracking(
+            clip, end_eff_names=["aux_1", "aux_2", "aux_3", "aux_4"], appendage_names=["aux_1", "aux_2", "aux_3", "aux_4", "torso"],
+            walker_body_names=[n for n in names["body"] if n != "world"], joint_names=names["joint"][1:],
+            center_of_mass="torso", model=m, clip_length=T, sub_clip_length=10, ref_traj_length=5, healthy_z_range=(0.2, 1.0),
+            num_envs=B, device=device)
     return env
 
 

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 def _env(B, lib=None):
     from vnl_brax_imitation_amd.envs.rodent import RodentTracking
 
-    return RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", _library=lib, **H.env_kwargs())
+    with H.backend(lib):
+        return RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", **H.env_kwargs())
 
 
 def test_spilling_build_matches_oracle_and_product_build():

@@ -36,9 +36,11 @@ def _env(B, real="float", device="cpu", **kw):
     from vnl_brax_imitation_amd.envs.humanoid import HumanoidTracking
 
     m = _model()
-    lib = H.hostsim_library(real) if device == "cpu" else None
-    return HumanoidTracking(PARAMS, clip_length=60, episode_length=20, reference_clip=_clip(m), model=m, num_envs=B, device=device,
-                            _library=lib, _dtype=torch.float64 if real == "double" else torch.float32, **kw)
+    import contextlib
+
+    with (H.hostsim_backend(real) if device == "cpu" else contextlib.nullcontext()):
+        return HumanoidTracking(PARAMS, clip_length=60, episode_length=20, reference_clip=_clip(m), model=m, num_envs=B,
+                                device=device, **kw)
 
 
 def _oracle(env, precision="f64"):

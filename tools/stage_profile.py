@@ -29,7 +29,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     lib = _lib.load_library(hb.build(profile=True))
-    env = RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", _library=lib, **H.env_kwargs())
+    with H.backend(lib):
+        env = RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", **H.env_kwargs())
     st = env.reset(0)
     g = torch.Generator().manual_seed(0)
     buf = (C.c_ulonglong * 40)()

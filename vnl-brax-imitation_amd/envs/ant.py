@@ -44,8 +44,7 @@ class AntTracking(RodentTracking):
     def __init__(self, params, healthy_z_range=(0.2, 1.0), reset_noise_scale=1e-2, clip_length: int = 250,
                  episode_length: int = 150, ref_traj_length: int = 5, termination_threshold: float = 0.9,
                  body_error_multiplier: float = 1.0, num_envs: int = 1, device: Any = "cuda", reference_clip=None,
-                 model: Optional[_mjcf.CompiledModel] = None, mjcf_path: str = "./assets/ant.xml", _library=None,
-                 _dtype: torch.dtype = torch.float32, **kwargs):
+                 model: Optional[_mjcf.CompiledModel] = None, mjcf_path: str = "./assets/ant.xml", **kwargs):
         params = dict(params or {})
         if str(params.get("solver", "cg")).lower() == "newton":
             warnings.warn("AntTracking: the Newton solver is not implemented; using CG with the same iteration counts")
@@ -75,7 +74,7 @@ class AntTracking(RodentTracking):
         if reference_clip is None:
             path = params.get("clip_path")
             reference_clip = _pp.ReferenceClip.load(path) if path and os.path.exists(path) else standing_clip(m, clip_length)
-        self._build(reference_clip, num_envs, device, _library, _dtype)
+        self._build(reference_clip, num_envs, device)
 
     @property
     def observation_size(self) -> int:

@@ -39,8 +39,7 @@ class HumanoidTracking(RodentTracking):
     def __init__(self, params, healthy_z_range=(1.0, 2.0), reset_noise_scale=1e-2, clip_length: int = 250,
                  episode_length: int = 150, ref_traj_length: int = 5, termination_threshold: float = 0.9,
                  body_error_multiplier: float = 1.0, num_envs: int = 1, device: Any = "cuda", reference_clip=None,
-                 model: Optional[_mjcf.CompiledModel] = None, mjcf_path: str = "./assets/humanoid.xml", _library=None,
-                 _dtype: torch.dtype = torch.float32, **kwargs):
+                 model: Optional[_mjcf.CompiledModel] = None, mjcf_path: str = "./assets/humanoid.xml", **kwargs):
         params = dict(params or {})
         self.sys = model if model is not None else _load_model(
             mjcf_path, None, params.get("solver", "cg"), int(params.get("iterations", 6)), int(params.get("ls_iterations", 6)))
@@ -65,7 +64,7 @@ class HumanoidTracking(RodentTracking):
         if reference_clip is None:
             path = params.get("clip_path")
             reference_clip = _pp.ReferenceClip.load(path) if path and os.path.exists(path) else standing_clip(m, clip_length)
-        self._build(reference_clip, num_envs, device, _library, _dtype)
+        self._build(reference_clip, num_envs, device)
 
     def reset(self, rng=None, *, start_frame=None, noise=None, clip_id=None, out=None):
         """humanoid.py:79-133: start_frame ~ U[0, clip_length - episode_length - ref_traj_length), no noise."""

@@ -27,6 +27,10 @@ from ..model import mjcf as _mjcf
 from .base import Env, PipelineState, State
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Test seam, outside every public signature: (library, dtype) that the envs constructed while it is set bind to instead of
+# csrc/libvnl.so -- the host-compiled PRODUCT source of tests/hostsim, or a regression build of it.  Set and cleared by
+# tests/helpers.py `backend(...)`; None in any product use, where construction fails loudly without a HIP device.
+_TEST_BACKEND = None
 _METRICS = ("rcom", "rvel", "rtrunk", "rquat", "ract", "rapp", "termination_error")
 
 
@@ -80,8 +84,6 @@ class RodentTracking(Env):
         num_envs: int = 1,
         device: Any = "cuda",
         model: Optional[_mjcf.CompiledModel] = None,
-        _library: Optional[C.CDLL] = None,
-        _dtype: torch.dtype = torch.float32,
         **kwargs,
     ):
         # --- model (rodent.py:39-63) --------------------------------------------------
@@ -107,7 +109,7 @@ class RodentTracking(Env):
         if self._sub_clip_length > self._clip_length:
             raise ValueError("episode_length cannot be greater than clip_length!")  # rodent.py:116-117
 
-        self._build(reference_clip, num_envs, device, _library, _dtype)
+        self._build(reference_clip, num_envs, device)
 
     # env-variant knobs (include/vnl.h VNL_ENV_*): RodentTracking's glue by default
     _env_flags = 0
@@ -115,8 +117,10 @@ class RodentTracking(Env):
     _reward_weights = None  # with ENV_WEIGHTS: (rcom, rvel, rtrunk, rquat, ract, rapp)
     _use_clip_com = False
 
-    def _build(self, reference_clip, num_envs, device, _library, _dtype):
+    def _build(self, reference_clip, num_envs, device, _library=None, _dtype=torch.float32):
         # everything set so far is configuration; what follows is per-instance device state (with_num_envs)
+        if _library is None and _TEST_BACKEND is not None:  # tests/helpers.py `backend(...)` only; never set by the product
+            _library, _dtype = _TEST_BACKEND
         self._config_attrs = dict(self.__dict__)
         self._build_args = (reference_clip, device, _library, _dtype)
         m = self.sys

@@ -125,7 +125,7 @@ def forward_kinematics_batch(model: mjcf.CompiledModel, qpos: np.ndarray):
     return q, xpos, xquat
 
 
-def forward_kinematics_device(model: mjcf.CompiledModel, qpos: np.ndarray, device="cuda", chunk: int = 4096, _library=None):
+def forward_kinematics_device(model: mjcf.CompiledModel, qpos: np.ndarray, device="cuda", chunk: int = 4096):
     """The same as forward_kinematics_batch on the GPU (float32): the frames go through `vnl_env_fk`, one frame per
     wavefront, `chunk` frames per launch (the batched FK kernel of SURVEY 8(f) f1).  Returns (qpos with normalised root
     quaternion, xpos (N, nbody, 3), xquat (N, nbody, 4), subtree centre of mass of the root body (N, 3))."""
@@ -145,7 +145,7 @@ def forward_kinematics_device(model: mjcf.CompiledModel, qpos: np.ndarray, devic
     body = [n for n in names["body"] if n != "world"]
     env = RodentTracking(dummy, end_eff_names=[], appendage_names=[], walker_body_names=body[:1], joint_names=[],
                          center_of_mass=body[0], model=model, clip_length=1, sub_clip_length=1, ref_traj_length=1,
-                         num_envs=B, device=device, _library=_library)
+                         num_envs=B, device=device)
     out_q, xpos, xquat, com = q.copy(), z(N, nbody, 3), z(N, nbody, 4), z(N, 3)
     st = None
     for a in range(0, N, B):
