@@ -367,9 +367,16 @@ def main() -> None:
         hbm_gbs = B_ALG * B / (kernel_ms * 1e-3) / 1e9
         valu_tflops = per_gpu_kernel_rate * F_ALG / 1e12
         traffic, traffic_src = None, None
-        if os.path.exists(TRAFFIC_FILE):
-            tf = json.load(open(TRAFFIC_FILE))
-            if int(tf.get("envs", 0)) == B:
+        tpath = next((p_ for p_ in (os.path.join(ROOT, "gpurun_out", "traffic_latest.json"), TRAFFIC_FILE) if os.path.exists(p_)), None)
+        if tpath:
+            import hashlib
+
+            tf = json.load(open(tpath))
+            hsh = hashlib.sha256()
+            for f in ("vnl_body.h", "vnl_lib.hip", "vnl_types.h"):
+                hsh.update(open(os.path.join(ROOT, "vnl-brax-imitation_amd", "csrc", f), "rb").read())
+            # a figure taken with other kernel sources (or another env count) is stale: reported as null, never as measured
+            if int(tf.get("envs", 0)) == B and tf.get("kernel_sources_sha256") == hsh.hexdigest():
                 traffic, traffic_src = float(tf["bytes_per_launch"]), tf.get("source")
         workload = ("humanoid imitation rollout (HumanoidTracking, synthetic standing clip), " if args.config == "humanoid" else
                     "rodent imitation rollout, ") + (
@@ -411,7 +418,8 @@ def main() -> None:
                 "traffic_source": traffic_src,
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": F_ALG * B,
-                "algorithmic_flops_note": "SURVEY 8(d) tree-sparse estimate, worst-case iteration counts",
+                "algorithmic_flops_note": "SURVEY 8(d) tree-sparse ESTIMATE at worst-case iteration counts, not a count of executed "
+                                          "flops: `achieved` and `frac` are upper bounds of the useful fp32 rate",
                 "algorithmic_bytes_per_launch": B_ALG * B,
                 "hbm_achieved_gbs": hbm_gbs,
                 "hbm_peak_gbs": HBM_PEAK_GBS,

@@ -55,3 +55,30 @@ def test_spilling_build_matches_oracle_and_product_build():
     worst = {k: float(P.per_env_scaled(outs[0][k], outs[1][k].astype(np.float64)).max()) for k in outs[0]}
     print("[spill vs product build, 3 steps] bitwise equal:", same, "worst scaled difference:", worst)
     assert all(same.values()), (same, worst)  # bit for bit, as DESIGN section 2 item 3 states
+
+
+def test_packed_factorisation_equals_the_plain_form_bit_for_bit():
+    """factor_pair on the device interleaves the two systems' rows (v_pk_fma_f32) and carries the rows 64.. as guests in
+    other lanes' registers; the plain form (the one the host simulation compiles, csrc/build.py --unpacked) performs the
+    same operations on the same operands in the same order per entry: three control steps must agree bit for bit."""
+    from vnl_brax_imitation_amd import _lib
+    from vnl_brax_imitation_amd.csrc import build as hip_build
+
+    path = hip_build.build(variant="unpacked")
+    B = 512
+    rng = np.random.default_rng(33)
+    sf = rng.integers(0, 235, B).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
+    acts = np.clip(0.3 * rng.standard_normal((3, B, 30)), -1, 1).astype(np.float32)
+    outs = []
+    for env in (_env(B, _lib.load_library(path)), _env(B)):
+        s = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+        for a in acts:
+            s = env.step(s, torch.from_numpy(a))
+        ps = s.pipeline_state
+        outs.append({k: getattr(ps, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc_warmstart", "xpos")} |
+                    {"obs": s.obs.cpu().numpy().copy(), "reward": s.reward.cpu().numpy().copy()})
+    same = {k: bool(np.array_equal(outs[0][k], outs[1][k])) for k in outs[0]}
+    worst = {k: float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()) for k in outs[0]}
+    print("\n[packed vs plain factor_pair, 3 steps, 512 envs] bitwise equal:", same, "largest difference:", worst)
+    assert all(same.values()), (same, worst)

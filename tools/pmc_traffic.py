@@ -27,6 +27,15 @@ fetch_kb, write_kb = avg(rd, "FETCH_SIZE"), avg(wr, "WRITE_SIZE")
 out = dict(envs=envs, fetch_kb=fetch_kb, write_kb=write_kb, bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0,
            source=label, note="FETCH_SIZE x2 (gfx950 read correction, upper bound for 4-B/lane accesses) + WRITE_SIZE, per launch")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = os.path.join(root, "gpurun_out", "traffic_latest.json")
-json.dump(out, open(path, "w"), indent=1)
+# fingerprint of the kernel sources the figure was taken with: bench.py drops the figure when the sources have changed since
+import hashlib  # noqa: E402
+
+h = hashlib.sha256()
+for f in ("vnl_body.h", "vnl_lib.hip", "vnl_types.h"):
+    h.update(open(os.path.join(root, "vnl-brax-imitation_amd", "csrc", f), "rb").read())
+out["kernel_sources_sha256"] = h.hexdigest()
+# gpurun_out/ travels back from the GPU box; profiles/ is what bench.py reads and what gets committed: write both
+for d in ("gpurun_out", "profiles"):
+    os.makedirs(os.path.join(root, d), exist_ok=True)
+    json.dump(out, open(os.path.join(root, d, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(out))

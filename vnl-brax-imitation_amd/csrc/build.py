@@ -13,13 +13,18 @@ OUT = os.path.join(HERE, "libvnl.so")
 # Diagnostic / regression builds of the SAME sources (never the product library, only loaded by tools/ and tests/):
 #   prof   -DVNL_PROFILE      per-stage s_memtime stamps (tools/stage_profile.py)
 #   knobs  -DVNL_STAGE_KNOBS  stage-repeat knob VNL_DBG_REPEAT + LDS padding knob (tools/stage_cost.py, tools/pmc_stage.sh)
+#   unpacked  -DVNL_FAC_UNPACKED: factor_pair in its plain form (regression build for the packed device form)
 #   spill  env kernels compiled under a 128-VGPR cap, which forces ~230 registers per lane to spill to scratch
 #          memory: results must not depend on spilling (tests/test_gpu_spill.py)
 VARIANTS = {
     "product": ("libvnl.so", []),
-    "prof": ("libvnl_prof.so", ["-DVNL_PROFILE"]),
-    "knobs": ("libvnl_knobs.so", ["-DVNL_STAGE_KNOBS"]),
+    # (the diagnostic variants carry extra code: held to the product's two waves per SIMD so that their timings stay comparable)
+    "prof": ("libvnl_prof.so", ["-DVNL_PROFILE", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
+    "knobs": ("libvnl_knobs.so", ["-DVNL_STAGE_KNOBS", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     "spill": ("libvnl_spill.so", ["-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(4,4)))"]),
+    # the two factorisations of a substep in the plain form (one lane set per 64 rows, one v_fma_f32 per system): the form the
+    # host simulation compiles; the product's packed form must agree with it bit for bit (tests/test_gpu_spill.py)
+    "unpacked": ("libvnl_unpacked.so", ["-DVNL_FAC_UNPACKED"]),
 }
 ENV_KERNELS = ("vnl_step_kernel", "vnl_reset_kernel")
 
@@ -75,6 +80,13 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, kno
         for k, v in seen.items():
             u = v[0]
             if u.get("ScratchSize [bytes/lane]", 0) != 0 or u["Occupancy [waves/SIMD]"] < 2:
+                if os.environ.get("VNL_ALLOW_SPILL") != "1":
+                    os.remove(out)
+                    raise RuntimeError(
+                        f"{k}: {u.get('VGPRs')} VGPRs, {u.get('ScratchSize [bytes/lane]')} B scratch per lane, "
+                        f"{u['Occupancy [waves/SIMD]']} waves/SIMD -- below the two waves per SIMD without spilling that the "
+                        "published numbers were measured with.  Results do not depend on spilling (tests/test_gpu_spill.py); "
+                        "this gate keeps a performance regression from shipping silently: set VNL_ALLOW_SPILL=1 to build anyway")
                 sys.stderr.write(f"[build] WARNING (performance): {k} uses {u.get('VGPRs')} VGPRs, "
                                  f"{u.get('ScratchSize [bytes/lane]')} B scratch per lane, "
                                  f"{u['Occupancy [waves/SIMD]']} waves/SIMD: below the two waves per SIMD without "

@@ -1064,6 +1064,164 @@ struct EnvWave {
     VNL_SYNC();
     VNL_PROF(9);
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VNL_FAC_UNPACKED)
+#define VNL_FAC_PACKED 1
+  // factor_pair, device form (same arithmetic per row, entry by entry: the two forms agree bit for bit -- tests/test_gpu_spill.py
+  // runs the -DVNL_FAC_UNPACKED build beside the product build):
+  //  * the two systems' rows are INTERLEAVED, (M, M + h diag(damping)) pairs in even/odd registers and in the scratch
+  //    lines, so every row update is one v_pk_fma_f32 for both systems (a wave alone issues a packed FMA in the time of a
+  //    plain one: tools/microbench/issue_rate.hip) and one ds_read_b128 brings two columns of both;
+  //  * no second lane set: a row 64.. (the rodent has nine, depth <= 13) rides as a GUEST in the registers of a lane whose own
+  //    row is shallow (host table m.fac_guest: host depth <= 12, guest depth <= 24), in column chunks 1-2, which the deep
+  //    rows of other lanes occupy anyway -- the guest's updates share those lanes' instructions, each lane reading ITS
+  //    pivot line with ITS multiplier.
+  typedef vreal v2r __attribute__((vector_size(2 * sizeof(vreal))));
+  template <int MAXD, bool GUESTS>
+  VNL_HD void factor_pair_packed(vreal h, vreal* g2) const {
+    static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
+    constexpr int CH = MAXD % 12 == 0 ? 12 : 16, NCH = MAXD / CH;
+    static_assert(!GUESTS || NCH == 3, "guest rows sit in chunks 1-2 of 3");
+    constexpr int LW = 2 * MAXD + 4;  // [(r1, r2) x MAXD | 1/pivot1, 1/pivot2 | pad]
+    v2r rr[MAXD];
+    const int sc = (L.Ma + 3) & ~3;  // Ma .. tmp2 are dead while factorising
+    const int nsteps = m.fac_steps;
+    // row A = this lane's own row; row B = its guest (or none)
+    const int a = (int)lane, g = GUESTS ? m.fac_guest[lane] : -1;
+    const bool okA = a < m.nv, hasB = g >= 0;
+    const int adrA = okA ? madr(a) : 0, depA = okA ? eadr(a) - adrA : 0;
+    const int adrB = hasB ? madr(g) : 0, depB = hasB ? eadr(g) - adrB : 0;
+    v2r dgA, dgB, i2;  // diagonals of both systems; i2 = (1 / D2 of row A, of row B) once they were pivots
+    {
+      const vreal d1 = okA ? s[L.LD + adrA] : vreal(1.);
+      dgA = v2r{d1, okA ? d1 + h * m.dof_damping[a] : vreal(1.)};
+      const vreal e1 = hasB ? s[L.LD + adrB] : vreal(1.);
+      dgB = v2r{e1, hasB ? e1 + h * m.dof_damping[hasB ? g : 0] : vreal(1.)};
+      i2 = v2r{vreal(0.), vreal(0.)};
+    }
+#pragma unroll
+    for (int c = 0; c < MAXD; c++) {
+      vreal x = c < depA ? s[L.LD + adrA + depA - c] : vreal(0.);
+      if (GUESTS && c >= CH && hasB) x = c - CH < depB ? s[L.LD + adrB + depB - (c - CH)] : vreal(0.);
+      rr[c] = v2r{x, x};
+    }
+    const int lineA = okA ? (m.dof_fslot[a] & 0xff) : 0, lineB = hasB ? (m.dof_fslot[g] & 0xff) : 0;
+    const int ftA = okA ? m.dof_ftime[a] : -1, ftB = hasB ? m.dof_ftime[g] : -1;
+    const unsigned char* mtA = m.fac_match + (size_t)(okA ? a : 0) * nsteps;
+    const unsigned char* mtB = m.fac_match + (size_t)(hasB ? g : 0) * nsteps;
+    unsigned nxtA = (okA && nsteps > 0) ? mtA[0] : 0u, nxtB = (hasB && nsteps > 0) ? mtB[0] : 0u;
+    VNL_SYNC();
+    VNL_PROF(7);
+    for (int step = 0; step < nsteps; step++) {
+      unsigned curA = nxtA, curB = nxtB;
+      nxtA = (okA && step + 1 < nsteps) ? mtA[step + 1] : 0u;  // prefetch
+      if (GUESTS) nxtB = (hasB && step + 1 < nsteps) ? mtB[step + 1] : 0u;
+      // ---- publish the rows that are pivots in this step: register chunk k -> line columns [CH k, CH k + CH) of the own row,
+      // a guest's chunks 1-2 -> columns [0, 2 CH) of ITS line
+      const bool pubA = ftA == step, pubB = GUESTS && ftB == step;
+      if (vnl_wave_any(pubA || pubB)) {
+        const int lA = sc + lineA * LW, lB = sc + lineB * LW;
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+          const bool guest_chunk = GUESTS && k > 0 && hasB;
+          const bool on = guest_chunk ? (pubB && depB > CH * (k - 1)) : (pubA && depA > CH * k);
+          if (on) {
+            vreal* dst = s + (guest_chunk ? lB + 2 * CH * (k - 1) : lA + 2 * CH * k);
+#pragma unroll
+            for (int c = 0; c < CH; c += 2)
+              st4a(dst + 2 * c, rr[CH * k + c][0], rr[CH * k + c][1], rr[CH * k + c + 1][0], rr[CH * k + c + 1][1]);
+          }
+        }
+        if (pubA) {
+          const vreal i1 = vnl_recip(dgA[0]), j2 = vnl_recip(dgA[1]);
+          s[lA + 2 * MAXD] = i1, s[lA + 2 * MAXD + 1] = j2;
+          s[L.dinv + a] = i1;
+          i2[0] = j2;
+        }
+        if (pubB) {
+          const vreal i1 = vnl_recip(dgB[0]), j2 = vnl_recip(dgB[1]);
+          s[lB + 2 * MAXD] = i1, s[lB + 2 * MAXD + 1] = j2;
+          s[L.dinv + g] = i1;
+          i2[1] = j2;
+        }
+      }
+      VNL_WAVE_FENCE();
+      // ---- absorb: row[c] -= (pivot[col of this row] / D) * pivot[c], both systems at once
+      // (measured: issuing every LDS read of a pass before its first multiply-add -- 48 more registers -- was 3 % SLOWER
+      // than this chunk-by-chunk form, 2.36 vs 2.29 ms per launch)
+      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
+        if (!vnl_wave_any((curA | curB) != 0u)) break;
+        const bool onA = curA != 0u, onB = GUESTS && curB != 0u;
+        const int kA = onA ? __builtin_ctz(curA) : 0, kB = onB ? __builtin_ctz(curB) : 0;
+        curA &= curA - 1u, curB &= curB - 1u;
+        const vreal* lnA = s + sc + kA * LW;
+        // chunk 0 belongs to row A in every lane: fetched together with the pivot entry and 1/D (one LDS round trip)
+        R4 x0[CH / 2];
+        v2r tA = v2r{vreal(0.), vreal(0.)}, rawA = tA;
+        if (onA) {
+#pragma unroll
+          for (int c = 0; c < CH; c += 2) x0[c / 2] = ld4a(lnA + 2 * c);
+          rawA = v2r{lnA[2 * depA], lnA[2 * depA + 1]};
+          tA = rawA * v2r{lnA[2 * MAXD], lnA[2 * MAXD + 1]};
+#pragma unroll
+          for (int c = 0; c < CH; c += 2) {
+            rr[c] -= tA * v2r{x0[c / 2].x, x0[c / 2].y};
+            rr[c + 1] -= tA * v2r{x0[c / 2].z, x0[c / 2].w};
+          }
+          dgA -= tA * rawA;
+        }
+        if constexpr (NCH > 1) {
+          // chunks 1 .. : row A's deeper columns, or the guest's columns [0, 2 CH) -- its own line, its own multiplier
+          v2r tB = tA;
+          const vreal* lnB = lnA;
+          bool on1 = onA && depA > CH, on2 = onA && depA > 2 * CH;
+          if (GUESTS && vnl_wave_any(hasB && onB)) {
+            const vreal* lg = s + sc + kB * LW;
+            if (hasB && onB) {
+              const v2r rawB = v2r{lg[2 * depB], lg[2 * depB + 1]};
+              tB = rawB * v2r{lg[2 * MAXD], lg[2 * MAXD + 1]};
+              dgB -= tB * rawB;
+              lnB = lg - 2 * CH;  // register column CH + c holds the guest's column c
+            }
+            if (hasB) on1 = onB, on2 = onB && depB > CH;
+          }
+#pragma unroll
+          for (int k = 1; k < NCH; k++) {
+            if (k == 1 ? on1 : on2) {
+#pragma unroll
+              for (int c = CH * k; c < CH * k + CH; c += 2) {
+                const R4 x = ld4a(lnB + 2 * c);
+                rr[c] -= tB * v2r{x.x, x.y};
+                rr[c + 1] -= tB * v2r{x.z, x.w};
+              }
+            }
+          }
+        }
+      }
+      VNL_WAVE_FENCE();
+    }
+    VNL_SYNC();
+    VNL_PROF(8);
+    // system 1 -> L.LD / L.dinv (unit-lower rows scaled by 1/D), system 2 -> the env's global scratch (euler())
+    if (okA) {
+      const vreal di = s[L.dinv + a];
+      s[L.LD + adrA] = dgA[0];
+      g2[adrA] = dgA[1], g2[m.nM + a] = i2[0];
+#pragma unroll
+      for (int c = 0; c < MAXD; c++)
+        if (c < depA && !(GUESTS && hasB && c >= CH)) s[L.LD + adrA + depA - c] = rr[c][0] * di, g2[adrA + depA - c] = rr[c][1] * i2[0];
+    }
+    if (GUESTS && hasB) {
+      const vreal di = s[L.dinv + g];
+      s[L.LD + adrB] = dgB[0];
+      g2[adrB] = dgB[1], g2[m.nM + g] = i2[1];
+#pragma unroll
+      for (int c = CH; c < MAXD; c++)
+        if (c - CH < depB) s[L.LD + adrB + depB - (c - CH)] = rr[c][0] * di, g2[adrB + depB - (c - CH)] = rr[c][1] * i2[1];
+    }
+    VNL_SYNC();
+    VNL_PROF(9);
+  }
+#endif
   // models whose two factorisations go through factor_pair (same conditions as the register route of factor(), plus
   // room for the second set of scratch lines in the eight dead vectors Ma .. tmp2 and for the factor copy in the pool)
   VNL_HD bool factor_pair_ok() const {
@@ -1071,14 +1229,22 @@ struct EnvWave {
     if (!m.eulerdamp || !m.fac_match) return false;
     const int room = 8 * nv - 3 - 8 * VNL_FAC_LINES;
     const bool regs = (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) ||
-                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16);
-    return regs && 2 * VNL_FAC_LINES * (md < 16 ? 16 : 36) <= room;
+                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16 && m.fac_guest);
+    // (m.fac_guest: the rows 64.. have a place in the packed device form; a model where they have none takes the
+    // one-system route in both builds, so that the two forms of factor_pair always run on the same models)
+    return regs && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
   }
   VNL_HD void factor_both(vreal h, vreal* g2) const {
     const int nv = m.nv, md = m.max_depth;
+#ifdef VNL_FAC_PACKED
+    if (nv <= VNL_LANES && md < 16) return factor_pair_packed<16, false>(h, g2);
+    if (nv <= VNL_LANES) return factor_pair_packed<36, false>(h, g2);
+    return factor_pair_packed<36, true>(h, g2);  // (factor_pair_ok(): the guests could be placed)
+#else
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_pair<VNL_ROWSETS_1, 16>(h, g2);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES) factor_pair<VNL_ROWSETS_1, 36>(h, g2);
     else factor_pair<VNL_ROWSETS_2, 36, 16>(h, g2);
+#endif
   }
 
   VNL_HD void factor(bool with_loop = true) const {
@@ -1315,6 +1481,7 @@ struct EnvWave {
     // keeps the forces aimed at it: broadcast LDS reads that pipeline, where one lane adding into the dofs paid a
     // dependent read-modify-write per actuator.
     const int frc = L.tmp2, adof = L.tmp;  // both free here
+    const bool listed = m.dof_act != nullptr;  // (host table: the <= 4 actuators of every dof, in actuator order)
     VNL_FOR(i, m.nu) {
       vreal ctrl = s[L.ctrl + i], a = ctrl;
       vreal tau = m.act_tau[i];
@@ -1323,17 +1490,23 @@ struct EnvWave {
         s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
       }
       s[frc + i] = m.act_gear[i] * m.act_gain[i] * a;
-      s[adof + i] = vreal(m.act_dof[i]);  // exact: dof < 2^24
+      if (!listed) s[adof + i] = vreal(m.act_dof[i]);  // exact: dof < 2^24
     }
     VNL_SYNC();
     vreal* gf = gqfrc_act();
     VNL_FOR(d, m.nv) {
       vreal fa = vreal(0.);
-      const vreal me = vreal(d);
+      if (listed) {
+        // the actuators aimed at this dof, packed by the host (index + 1 per byte, ascending: the same summation order as
+        // the walk over all actuators below, which models with more than four actuators on one dof still take)
+        for (unsigned pk = (unsigned)m.dof_act[d]; pk != 0u; pk >>= 8) fa += s[frc + (int)(pk & 0xffu) - 1];
+      } else {
+        const vreal me = vreal(d);
 #pragma unroll 6
-      for (int i = 0; i < m.nu; i++) {
-        const vreal f = s[frc + i];
-        if (s[adof + i] == me) fa += f;
+        for (int i = 0; i < m.nu; i++) {
+          const vreal f = s[frc + i];
+          if (s[adof + i] == me) fa += f;
+        }
       }
       gf[d] = fa;
       vreal v = s[L.smooth + d] + fa;

@@ -417,6 +417,23 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       d.fac_nleaf |= deep1 << 8;
     }
     UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
+    {  // guests of factor_pair_packed: rows 64.. placed into lanes whose own row is shallow (deepest guests first)
+      d.fac_guest = nullptr;
+      if (nv > 64 && nv <= 128) {
+        std::vector<int> guest(64, -1), order;
+        for (int j = 64; j < nv; j++) order.push_back(j);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return depth[x] > depth[y]; });
+        bool ok = true;
+        for (int j : order) {
+          int host = -1;
+          for (int l = 0; l < 64 && host < 0; l++)
+            if (guest[l] < 0 && depth[l] <= 12) host = l;
+          if (host < 0 || depth[j] > 24) ok = false;
+          else guest[host] = j;
+        }
+        if (ok) UPI(fac_guest, guest)
+      }
+    }
     {  // fac_match[a][t]: the scratch lines whose pivot of step t lies strictly below row a (factor_pair absorbs them)
       const int nst = d.fac_steps;
       std::vector<unsigned char> match((size_t)nv * (nst > 0 ? nst : 1), 0);
@@ -429,6 +446,18 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
+  {  // per dof: the actuators that drive it (smooth_forces gathers instead of walking all actuators per dof)
+    std::vector<int> packed(nv, 0), cnt(nv, 0);
+    bool ok = nu < 255;
+    for (int a = 0; a < nu && ok; a++) {
+      const int dd = I("act_dof")[a];
+      if (dd < 0 || dd >= nv) continue;
+      if (cnt[dd] == 4) ok = false;
+      else packed[dd] |= (a + 1) << (8 * cnt[dd]++);
+    }
+    d.dof_act = nullptr;
+    if (ok) UPI(dof_act, packed)
+  }
   UPF(act_tau, F("act_tau")) UPF(act_gear, F("act_gear"))
   {
     std::vector<double> lo(nu), hi(nu);

@@ -910,6 +910,18 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   int prev = 0;
   PCHK(hipGetDevice(&prev));
   if (prev != u->device) PCHK(hipSetDevice(u->device));
+  // Every return path -- the error returns of PCHK / rc included -- restores the caller's device and joins the second
+  // stream back into the caller's (an unjoined fork would invalidate a hipGraph capture of the caller's stream).
+  struct Scope {
+    int prev, device;
+    hipStream_t st, s2;
+    hipEvent_t ev;
+    bool forked = false, done = false;
+    ~Scope() {
+      if (forked && !done && hipEventRecord(ev, s2) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+      if (prev != device) (void)hipSetDevice(prev);
+    }
+  } scope{prev, u->device, (hipStream_t)stream, u->s2, u->ev[3]};
   // Two chains per step: the value MLP (three big GEMMs forward, four backward) on the caller's stream, the intention
   // network (twenty small, latency-bound launches) beside it on the handle's second stream; they meet at the loss head and
   // at the final reduction.  The fork / join events make the second stream part of a hipGraph capture of the caller's.
@@ -950,6 +962,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   }
   PCHK(hipEventRecord(u->ev[0], st));
   PCHK(hipStreamWaitEvent(sp2, u->ev[0], 0));
+  scope.forked = true;
   // value MLP over the T*B rows + the B bootstrap rows (ppo_networks.py:114-118; swish)
   const int nvl = (int)u->val.size();  // hidden layers + the output layer
   {
@@ -1012,13 +1025,14 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     // GAE needs the value outputs only: it runs while the intention network's forward is still in flight
     int rc = vnl_ppo_head_phase_(&a, u->headws, stream, 1);
     if (rc != VNL_OK) return rc;
-    // metrics[8] = prediction_corr (a metric only), in the same slack; 0 when the 2T rows do not fit in LDS
+    // metrics[8] = prediction_corr (a metric only), in the same slack; NaN ("not computed", never a fake 0.0) when the 2T
+    // rows do not fit in LDS -- the same rule as the torch backend (intention_losses.py: _corr_fits)
     const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
     if (lds <= 60 * 1024)
       hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(VNL_CORR_THREADS), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
                          u->T, u->B, metrics + 8);
     else
-      PCHK(hipMemsetAsync(metrics + 8, 0, sizeof(float), st));
+      PCHK(hipMemsetAsync(metrics + 8, 0xff, sizeof(float), st));  // 0xffffffff: a quiet NaN
     PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
     rc = vnl_ppo_head_phase_(&a, u->headws, stream, 2);
     if (rc != VNL_OK) return rc;
@@ -1096,8 +1110,8 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   PCHK(hipEventRecord(u->ev[3], sp2));
   PCHK(hipStreamWaitEvent(st, u->ev[3], 0));
   reduce_pool(pool, st);  // the value MLP's split-K weight / bias gradients, summed in a fixed order by one launch
+  scope.done = true;  // joined above
   hipError_t e = hipGetLastError();
-  if (prev != u->device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return pfail(VNL_ERR_HIP, hipGetErrorString(e));
   return VNL_OK;
 }

@@ -60,12 +60,15 @@ struct DevModel {
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
   const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot; scratch line | one leaf under a << 8 | mask of all leaves under a << 16 */
+  const int* fac_guest;              /* [64] row 64.. that rides in lane l's registers during factor_pair_packed (-1: none); null if
+                                        the model has no such rows or they cannot be placed (host depth <= 12, guest depth <= 24) */
   const unsigned char* fac_match;    /* [nv][fac_steps]: bit k set = row a absorbs the pivot published in scratch line k in that step */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
   const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
   const vreal *dof_armature, *dof_damping;
   // actuators
   const int *act_dof, *act_limited;
+  const int* dof_act; /* [nv] the actuators aimed at each dof: (index + 1) per byte, ascending, 0 = none; null if some dof has more than 4 */
   const vreal *act_gain, *act_tau, *act_lo, *act_hi, *act_gear;
   // collidable geoms (all against the one plane); contact c belongs to geom con_geom[c]
   const int *cg_type, *cg_body, *cg_conadr, *cg_ncon, *con_geom;

@@ -59,8 +59,8 @@ def _fusable(env):
 
 
 def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int, extra_fields) -> Tuple[State, Transition]:
-    """Same results as the generic loop below (tests compare the two), 3 launches per step besides the
-    policy: observation row copy, env step kernel, vnl_rollout_post."""
+    """Same results as the generic loop below (tests compare the two), 2 launches per step besides the
+    policy: the env step kernel and vnl_rollout_post (which also writes the Transition's observation row)."""
     import ctypes as C
 
     from .. import _lib

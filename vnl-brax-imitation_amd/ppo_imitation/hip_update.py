@@ -15,11 +15,18 @@ from .acting import Transition
 
 def supported(ppo_network) -> bool:
     """The fused update implements exactly the networks of make_intention_ppo_networks with the running-statistics
-    normaliser or the identity as observation preprocessor."""
-    return bool(getattr(ppo_network, "hip_ok", False)) and ppo_network.policy_module is not None and \
-        ppo_network.value_module is not None and max(ppo_network.policy_module.encoder_layers +
-                                                     ppo_network.policy_module.decoder_layers +
-                                                     ppo_network.value_module.sizes) <= 1024
+    normaliser or the identity as observation preprocessor, within the limits vnl_ppo_update_create checks (csrc/vnl_ppo.hip):
+    1..8 layers per stack, widths <= 1024, the decoder's last layer = the distribution's 2 x action_size parameters."""
+    if not (bool(getattr(ppo_network, "hip_ok", False)) and ppo_network.policy_module is not None and
+            ppo_network.value_module is not None):
+        return False
+    pol, val, dist = ppo_network.policy_module, ppo_network.value_module, ppo_network.parametric_action_distribution
+    stacks = (list(pol.encoder_layers), list(pol.decoder_layers), list(val.sizes[:-1]))
+    if any(not (1 <= len(s) <= 8) for s in stacks):
+        return False
+    if max(w for s in stacks for w in s) > 1024:
+        return False
+    return pol.decoder_layers[-1] == 2 * dist.event_size
 
 
 class HipPPOUpdate:
@@ -34,6 +41,8 @@ class HipPPOUpdate:
         sp.traj_size, sp.obs_size, sp.action_size, sp.latent_size = pol.traj_size, pol.obs_size, dist.event_size, pol.latents
         sp.num_encoder_layers, sp.num_decoder_layers = len(pol.encoder_layers), len(pol.decoder_layers)
         sp.num_value_layers = len(val.sizes) - 1
+        if dev.index is None:  # a bare 'cuda': the CURRENT device, not GPU 0
+            dev = torch.device("cuda", torch.cuda.current_device())
         for i, h in enumerate(pol.encoder_layers):
             sp.encoder_layers[i] = h
         for i, h in enumerate(pol.decoder_layers):
@@ -42,7 +51,7 @@ class HipPPOUpdate:
             sp.value_layers[i] = h
         self.T, self.B, self.device = T, B, dev
         self.h = C.c_void_p()
-        _lib.check(self.lib, self.lib.vnl_ppo_update_create(C.byref(sp), T, B, dev.index or 0, C.byref(self.h)))
+        _lib.check(self.lib, self.lib.vnl_ppo_update_create(C.byref(sp), T, B, dev.index, C.byref(self.h)))
         self.num_params = int(self.lib.vnl_ppo_update_num_params(self.h))
         assert self.num_params == ppo_network.policy_network.layout.size + ppo_network.value_network.layout.size
         self.normalizes = bool(ppo_network.normalizes)

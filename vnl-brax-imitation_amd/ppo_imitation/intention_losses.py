@@ -31,6 +31,13 @@ def _corrcoef(x: torch.Tensor) -> torch.Tensor:
     return (c / (d[:, None] * d[None, :])).clamp(-1.0, 1.0)
 
 
+def _corr_fits(T: int, B: int) -> bool:
+    """prediction_corr (a 2T x 2T correlation matrix later averaged, reference intention_losses.py:186-188) is computed when
+    the 2T rows of B samples fit the HIP kernel's LDS budget -- ONE rule for both update backends (csrc/vnl_ppo.hip,
+    prediction_corr_kernel); otherwise the metric is NaN ("not computed"), never a fake 0.0."""
+    return (2 * T * B + 2 * T) * 4 <= 60 * 1024
+
+
 def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_: float = 1.0,
                 discount: float = 0.99):
     """intention_losses.py:26-87; inputs time-major [T, B]; returns (vs, advantages), no gradient."""
@@ -163,7 +170,7 @@ def compute_ppo_intention_loss(
             data.discount, draw("entropy", (T, B, dist.event_size)), cfg, lib)
         with torch.no_grad():
             rewards = data.reward * reward_scaling
-            prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if T * 2 <= 256 else torch.zeros((), device=dev)
+            prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if _corr_fits(T, vs.shape[1]) else torch.full((), float('nan'), device=dev)
         return total_loss, {"total_loss": mt[0], "policy_loss": mt[1], "v_loss": mt[2], "entropy_loss": mt[3],
                             "kl_loss_intention": mt[4], "prediction_corr": prediction_corr, "explained_variance": mt[5]}
 
@@ -194,7 +201,7 @@ def compute_ppo_intention_loss(
     with torch.no_grad():
         explained_variance = 1.0 - (v_loss / rewards.var(unbiased=False))
         # jnp.corrcoef(vs, rewards) is a (2T x 2T) matrix that the trainer later averages (:189, C.14)
-        prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if T * 2 <= 256 else torch.zeros((), device=dev)
+        prediction_corr = _corrcoef(torch.cat([vs, rewards], dim=0)).mean() if _corr_fits(T, vs.shape[1]) else torch.full((), float('nan'), device=dev)
     return total_loss, {
         "total_loss": total_loss.detach(),
         "policy_loss": policy_loss.detach(),

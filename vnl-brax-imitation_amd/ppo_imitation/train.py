@@ -216,6 +216,19 @@ def train(
     use_hip_update = update_backend == "hip" or (update_backend == "auto" and device.type == "cuda" and
                                                   hip_update.supported(ppo_network))
     hip_upd: Dict[Any, Any] = {}
+    if use_hip_update and update_backend == "auto":
+        # "auto" never raises for a network the library turns down: the handle of the minibatch shape is made up front and the
+        # torch path taken if vnl_ppo_update_create refuses it ("hip" still fails loudly)
+        from .. import _lib as _vnl_lib
+
+        try:
+            hip_upd[(unroll_length, local_batch)] = hip_update.HipPPOUpdate(
+                ppo_network, unroll_length, local_batch, device, entropy_cost=entropy_cost, discounting=discounting,
+                reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+                normalize_advantage=normalize_advantage, kl_weight=kl_weight)
+        except _vnl_lib.VnlError as e:
+            logging.warning("hand-written PPO update unavailable for this network (%s): using the torch update", e)
+            use_hip_update = False
     _METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "entropy_loss", "kl_loss_intention", "explained_variance")
 
     def hip_grad(data_tm: acting.Transition, normalizer_params, noise) -> Metrics:
