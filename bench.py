@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-autoreset", action="store_true", help="main measurement without the auto-reset wrapper")
     ap.add_argument("--no-free-running", action="store_true", help="skip the additional free-running measurement")
     ap.add_argument("--random-actions", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="issue the unroll's launches from Python instead of replaying the "
+                    "captured hipGraph (the round-2 form of the hot path)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` sub-record (full PPO training step)")
     ap.add_argument("--train-steps", type=int, default=3, help="training steps timed for the `train_step` sub-record")
     ap.add_argument("--train-step-multi", action="store_true", help="also run the `train_step` leg with --gpus > 1 (RCCL "
@@ -310,24 +312,32 @@ def main() -> None:
         if args.random_actions:
             actions = torch.clamp(0.3 * torch.randn((steps + warmup, B, base.action_size), generator=gen), -1.0, 1.0).to(dev)
 
-            def run(k0, n, timed):
+            graphed = None
+
+            def run(k0, n, timed, events=False):
                 nonlocal state
-                k_ev[0] = 0 if timed else None
-                base.step = step_hook if timed else orig_step
+                k_ev[0] = 0 if events else None
+                base.step = step_hook if events else orig_step
                 for k in range(n):
                     state = env.step(state, actions[k0 + k])
                 base.step = orig_step
         else:
             extra = ("truncation", "traj") if autoreset else ("traj",)  # truncation comes from EpisodeWrapper
+            # the unroll of 20 control steps as the trainer runs it: ONE hipGraph replay (acting.GraphedUnroll, bit-identical to
+            # the eager loop: tests/test_fused_rollout.py); a remainder of steps % 20 and the free-running leg run eagerly
+            graphed = acting.GraphedUnroll(env, state, policy, gdev, unroll, extra_fields=extra) if (autoreset and not args.eager) else None
 
-            def run(k0, n, timed):
+            def run(k0, n, timed, events=False):
                 nonlocal state
-                k_ev[0] = 0 if timed else None
-                base.step = step_hook if timed else orig_step
+                k_ev[0] = 0 if events else None
+                base.step = step_hook if events else orig_step
                 done = 0
                 while done < n:
                     chunk = min(unroll, n - done)
-                    state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=extra)
+                    if graphed is not None and chunk == unroll and not events:
+                        state, _ = graphed()
+                    else:
+                        state, _ = acting.generate_unroll(env, state, policy, gdev, chunk, extra_fields=extra)
                     done += chunk
                 base.step = orig_step
 
@@ -340,20 +350,31 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        run(warmup, steps, True)
+        run(warmup, steps, True, events=graphed is None)
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
             torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         base.kernel_events = None
+        if graphed is not None:
+            # HIP events recorded inside a captured graph cannot be timed: the step kernel's launch duration comes from an
+            # eager re-run of the same hot path on the same envs right after the timed region (`kernel_ms_source`)
+            nk = min(steps, 40)
+            ev = ev[:nk]
+            if args.random_actions:
+                run(0, nk, False, events=True)
+            else:
+                run(warmup, nk, False, events=True)
+            torch.cuda.synchronize(dev)
+            base.kernel_events = None
         if distributed:
             t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         return dict(dt=dt, kernel_ms=kernel_ms, finite=bool(torch.isfinite(state.obs).all().item()),
-                    done_frac=float(state.done.float().mean().item()))
+                    done_frac=float(state.done.float().mean().item()), graphed=graphed is not None)
 
     main_m = measure(not args.no_autoreset, args.steps, args.warmup)
     free_m = None
@@ -384,7 +405,8 @@ def main() -> None:
                      f"{args.clips} synthesised clips (random clip per env), ") +
                     f"{B} envs/GPU: " + ("random actions -> " if args.random_actions else "intention-policy forward (HIP) -> ") +
                     f"{type(base).__name__}.step (5 substeps, CG 6/6) -> " + f"auto-reset {'off' if args.no_autoreset else 'on'}" +
-                    ("" if args.random_actions else " -> Transition logging (unroll 20)"))
+                    ("" if args.random_actions else " -> Transition logging (unroll 20" +
+                     (", the 20 steps replayed as one captured hipGraph)" if main_m["graphed"] else ")")))
         out = {
             "metric": ("env-steps/sec (whole node), rodent imitation, num_envs=4096/GPU" if args.config == "rodent" else
                        "env-steps/sec (whole node), humanoid imitation, num_envs=1024/GPU (not the headline metric)"),
@@ -417,6 +439,9 @@ def main() -> None:
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel_ms": kernel_ms,
+                "kernel_ms_source": ("HIP events around the step-kernel launches of an eager re-run of the hot path right after "
+                                     "the timed region (events inside the replayed hipGraph cannot be timed)" if main_m["graphed"]
+                                     else "HIP events around the step-kernel launches of the timed region, on the launch stream"),
                 "algorithmic_flops_per_launch": F_ALG * B,
                 "algorithmic_flops_note": "SURVEY 8(d) tree-sparse ESTIMATE at worst-case iteration counts, not a count of executed "
                                           "flops: `achieved` and `frac` are upper bounds of the useful fp32 rate",

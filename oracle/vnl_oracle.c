@@ -124,6 +124,7 @@ typedef struct {
 typedef struct orc_model {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc;
   int iterations, ls_iterations, eulerdamp;
+  int solver_newton; /* opt.solver == NEWTON (reference configs/env_config.yaml:16-21, the ant): Mgrad = H^-1 grad, search = -Mgrad */
   real timestep, tolerance, ls_tolerance, impratio, meaninertia;
   real gravity[3];
   /* bodies */
@@ -211,6 +212,7 @@ int orc_model_create(const void *blob, size_t n, orc_model **out) {
   m->iterations = (int)blob_scalar(b, n, "iterations");
   m->ls_iterations = (int)blob_scalar(b, n, "ls_iterations");
   m->eulerdamp = (int)blob_scalar(b, n, "eulerdamp");
+  m->solver_newton = (int)blob_scalar(b, n, "solver_newton");
   m->timestep = (real)blob_scalar(b, n, "timestep");
   m->tolerance = (real)blob_scalar(b, n, "tolerance");
   m->ls_tolerance = (real)blob_scalar(b, n, "ls_tolerance");
@@ -921,9 +923,31 @@ static void slv_update_constraint(const orc_model *m, const orc_data *d, slv_ctx
   c->cost_scale = (real)0.5 * cost + (real)0.5 * gs;
 }
 
+/* solver._update_gradient [UPSTREAM mjx/_src/solver.py]: CG preconditions with M^-1 (the factor of qM); NEWTON with the
+ * Hessian of the cost at the current active set, H = qM + J' diag(efc_D * active) J, dense Cholesky (cho_factor /
+ * cho_solve), as MJX does on its dense route. */
 static void slv_update_gradient(const orc_model *m, const orc_data *d, slv_ctx *c) {
-  for (int i = 0; i < m->nv; i++) c->grad[i] = c->Ma[i] - d->qfrc_smooth[i] - c->qfrc_constraint[i];
-  solve_m(m, d, c->Mgrad, c->grad);
+  int nv = m->nv, ne = m->nefc;
+  for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - d->qfrc_smooth[i] - c->qfrc_constraint[i];
+  if (!m->solver_newton) {
+    solve_m(m, d, c->Mgrad, c->grad);
+    return;
+  }
+  real *H = (real *)malloc(sizeof(real) * 2 * nv * nv), *Lh = H + nv * nv;
+  memcpy(H, d->qM, sizeof(real) * nv * nv);
+  for (int r = 0; r < ne; r++) {
+    if (!(c->Jaref[r] < 0) || d->efc_D[r] == 0) continue;
+    const real *J = d->efc_J + (size_t)r * nv;
+    for (int i = 0; i < nv; i++) {
+      if (J[i] == 0) continue;
+      real w = d->efc_D[r] * J[i];
+      for (int j = 0; j < nv; j++) H[i * nv + j] += w * J[j];
+    }
+  }
+  chol_factor(Lh, H, nv);
+  memcpy(c->Mgrad, c->grad, sizeof(real) * nv);
+  chol_solve(Lh, c->Mgrad, nv);
+  free(H);
 }
 
 static void slv_init(const orc_model *m, const orc_data *d, slv_ctx *c, const real *qacc) {
@@ -1230,6 +1254,7 @@ void orc_solve(const orc_model *m, orc_data *d) {
     for (int i = 0; i < nv; i++) num += c.grad[i] * (c.Mgrad[i] - prev_Mgrad[i]), den += prev_grad[i] * prev_Mgrad[i];
     real beta = num / (den > MJ_MINVAL ? den : MJ_MINVAL);
     if (beta < 0) beta = 0;
+    if (m->solver_newton) beta = 0; /* solver.solve: search = -Mgrad */
     for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i] + beta * c.search[i];
     niter++;
   }

@@ -29,7 +29,7 @@ for _ in range(2):
     s = h.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 21)), -1, 1).astype(np.float32)))
 print("humanoid ok", bool(torch.isfinite(s.obs).all()))
 am = mjcf.CompiledModel.load(os.path.join(H.ROOT, "vnl-brax-imitation_amd", "data", "ant.npz"))
-a = AntTracking(dict(solver="cg", iterations=6, ls_iterations=6), model=am, num_envs=2, device="cpu")
+a = AntTracking(dict(solver="newton", iterations=1, ls_iterations=4), model=am, num_envs=2, device="cpu")  # the Newton branch too
 s = a.reset()
 for _ in range(2):
     s = a.step(s, torch.from_numpy(np.clip(0.3 * rng.standard_normal((2, 8)), -1, 1).astype(np.float32)))

@@ -27,14 +27,17 @@ def _clip(m, T=60):
     return pp.process_qpos(m, q, max_qvel=20.0, dt=0.02)
 
 
-def _env(B, real="float", device="cpu", **kw):
+NEWTON = dict(solver="newton", iterations=1, ls_iterations=4)  # reference configs/env_config.yaml:16-21
+
+
+def _env(B, real="float", device="cpu", params=None, **kw):
     from vnl_brax_imitation_amd import envs
 
     m = mjcf.CompiledModel.load(ANT_NPZ)
     import contextlib
 
     with (H.hostsim_backend(real) if device == "cpu" else contextlib.nullcontext()):
-        return envs.get_environment("ant", params=PARAMS, clip_length=60, episode_length=20, reference_clip=_clip(m), model=m,
+        return envs.get_environment("ant", params=params or PARAMS, clip_length=60, episode_length=20, reference_clip=_clip(m), model=m,
                                     num_envs=B, device=device, **kw)
 
 
@@ -136,7 +139,7 @@ def _config0_rollout(device, steps=250, B=64, seed=0):
     seed 0, 250 control steps; pass = runs, finite, deterministic)."""
     from vnl_brax_imitation_amd.envs.wrappers import wrap
 
-    env = _env(B, device=device)
+    env = _env(B, device=device, params=NEWTON)  # the reference's ant solver: Newton, 1 iteration, 4 line-search iterations
     w = wrap(env, episode_length=20)
     st = w.reset(seed)
     g = torch.Generator().manual_seed(seed)
@@ -164,3 +167,92 @@ def test_config0_ant_random_action_rollout_on_gpu():
     r2, o2, d2 = _config0_rollout("cuda:0")
     assert torch.equal(r1, r2) and torch.equal(o1, o2) and d1 == d2
     assert d1 > 0
+
+
+def _newton_inputs(B, seed=4):
+    rng = np.random.default_rng(seed)
+    return [np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1) for _ in range(4)]
+
+
+def test_newton_oracle_solves_the_hessian_system_and_differs_from_cg():
+    """The oracle's Newton route on its own terms (solver.py _update_gradient, NEWTON): after a forward pass with one
+    iteration, Mgrad-based search direction = -H^-1 grad with H = qM + J' diag(D active) J, checked by a dense NumPy solve of
+    the same system at the START point, and the step taken differs from the CG step (a different algorithm, not a no-op)."""
+    B = 1
+    en, ec = _env(B, "double", params=NEWTON), _env(B, "double", params=dict(solver="cg", iterations=1, ls_iterations=4))
+    on, oc = _oracle(en), _oracle(ec)
+    acts = _newton_inputs(B)
+    sn, sc = on.env_reset(np.zeros(B, np.int32), np.zeros((B, 15))), oc.env_reset(np.zeros(B, np.int32), np.zeros((B, 15)))
+    for a in acts:
+        on.env_step(sn, a), oc.env_step(sc, a)
+    assert np.isfinite(sn["qpos"]).all()
+    assert np.abs(sn["qvel"] - sc["qvel"]).max() > 1e-6  # Newton and CG with 1 iteration take different steps
+    # dense check of one Newton solve: set the oracle's single-env data to the last state and run forward
+    on.set(qpos=sn["qpos"][0], qvel=sn["qvel"][0], act=np.zeros(8), ctrl=acts[-1][0], qacc_warmstart=sn["qacc_warmstart"][0])
+    on.call("forward")
+    nv, ne = 14, int(en.sys.scalars["nefc"])
+    M, J = on.field("qM").reshape(nv, nv), on.field("efc_J").reshape(ne, nv)
+    D, aref = on.field("efc_D"), on.field("efc_aref")
+    fs, a0, aw = on.field("qfrc_smooth"), on.field("qacc_smooth"), sn["qacc_warmstart"][0]
+
+    def cost(a):
+        r = J @ a - aref
+        return 0.5 * np.sum(D * r * r * (r < 0)) + 0.5 * (M @ a - fs) @ (a - a0)
+
+    start = aw if cost(aw) < cost(a0) else a0
+    r = J @ start - aref
+    act_ = (r < 0) & (D != 0)
+    grad = M @ start - fs - J.T @ (D * -r * act_)
+    Hm = M + (J.T * (D * act_)) @ J
+    search = -np.linalg.solve(Hm, grad)
+    step = on.field("qacc") - start  # one iteration: qacc = start + alpha * search
+    if np.abs(step).max() > 0:
+        cosang = step @ search / (np.linalg.norm(step) * np.linalg.norm(search))
+        assert cosang > 1 - 1e-9, cosang  # the step is along the Newton direction
+    assert cost(on.field("qacc")) <= cost(start) + 1e-12
+
+
+def test_ant_env_newton_float64_build_matches_oracle():
+    """BASELINE configs[0]'s solver (Newton, 1 iteration, 4 line-search iterations; reference envs/ant.py:40-47 reading
+    configs/env_config.yaml:16-21): the product source compiled for the host in float64 against the dense oracle."""
+    B = 6
+    env = _env(B, "double", params=NEWTON)
+    assert int(env.sys.scalars["solver_newton"]) == 1 and int(env.sys.scalars["iterations"]) == 1
+    st = env.reset()
+    o = _oracle(env)
+    ost = o.env_reset(np.zeros(B, np.int32), np.zeros((B, 15)))
+    ps = st.pipeline_state
+    for k in ("qpos", "qvel", "xpos", "qacc_warmstart"):
+        assert H.scaled_err(getattr(ps, k).reshape(B, -1).numpy(), ost[k]) < 1e-10, k
+    for act in _newton_inputs(B):
+        st = env.step(st, torch.from_numpy(act))
+        o.env_step(ost, act)
+        assert H.scaled_err(ps.qpos.numpy(), ost["qpos"]) < 1e-9 and H.scaled_err(ps.qvel.numpy(), ost["qvel"]) < 1e-8
+        assert H.scaled_err(ps.qacc_warmstart.numpy(), ost["qacc_warmstart"]) < 1e-7
+        assert np.abs(st.reward.numpy() - ost["reward"]).max() < 1e-7 and np.array_equal(st.done.numpy(), ost["done"])
+    assert float(np.abs(ps.qvel.numpy()).max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_ant_env_newton_on_gpu():
+    """The Newton branch of EnvWave::solve on the device: one control step against the oracles following the product's
+    line-search decisions (same bounds as the CG test above) and three more steps finite and deterministic."""
+    B = 256
+    env = _env(B, device="cuda:0", params=NEWTON)
+    rng = np.random.default_rng(3)
+    sf, noise = np.zeros(B, np.int32), np.zeros((B, 15), np.float32)
+    act = np.clip(0.5 * rng.standard_normal((B, 8)), -1, 1).astype(np.float32)
+    o64, o32 = _oracle(env, "f64"), _oracle(env, "f32")
+    st, err, dev, rep, ost = P.control_step_follow(env, o64, o32, sf, noise, act)
+    print("\n[ant env, Newton 1/4, control step, 256 envs] " + ", ".join(f"{k}: max {v.max():.2e} median {np.median(v):.2e}" for k, v in err.items()))
+    P.check_control_step(err, dev, rep, max_flipped=B // 8)
+    causes = P.flip_causes(rep)
+    assert int(causes["other"].sum()) <= max(2, B // 50), causes
+    print("   vs the natural oracle:", P.natural_check(st, o64, o32, act))
+    outs = []
+    for _ in range(2):
+        s = env.reset()
+        for k in range(3):
+            s = env.step(s, torch.from_numpy(act))
+        outs.append(s.pipeline_state.qvel.clone())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

@@ -57,3 +57,41 @@ def test_fused_post_matches_generic_wrappers_gpu(reset_info):
     dev = torch.device("cuda:0")
     _compare(lambda B: RodentTracking(H.reference_clip(), num_envs=B, device=dev, **H.env_kwargs()), dev, reset_info,
              B=130, T=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reset_info", [False, True])
+def test_graphed_unroll_equals_the_eager_unroll_bit_for_bit(reset_info):
+    """acting.GraphedUnroll: the unroll captured into ONE hipGraph and replayed (policy launches, env step kernels,
+    vnl_rollout_post, the noise draws) against the eager fused loop: every Transition leaf and the carried env state of
+    three consecutive unrolls, bit for bit -- same kernels, same arguments, same Philox stream."""
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
+
+    dev = torch.device("cuda:0")
+    make_env = lambda B: RodentTracking(H.reference_clip(), num_envs=B, device=dev, **H.env_kwargs())  # noqa: E731
+    B, T, extra = 130, 6, ("truncation", "traj")
+    out = []
+    for graphed in (False, True):
+        env, policy = _setup(B, reset_info, 4, make_env, dev)
+        torch.manual_seed(123)
+        state = env.reset(torch.Generator().manual_seed(5))
+        key = torch.Generator(device=dev).manual_seed(11)
+        g = acting.GraphedUnroll(env, state, policy, key, T, extra_fields=extra) if graphed else None
+        datas = []
+        for _ in range(3):
+            if graphed:
+                state, data = g()
+            else:
+                state, data = acting.generate_unroll(env, state, policy, key, T, extra_fields=extra, fused=True)
+            datas.append([x.clone() for x in acting._leaves(data)])  # (the graph's buffers are overwritten by the next replay)
+        out.append((state, datas, key.get_state().clone()))
+    (s0, d0, k0), (s1, d1, k1) = out
+    for a_, b_ in zip(d0, d1):
+        for a, b in zip(a_, b_):
+            assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(k0, k1)  # the generator's stream advanced exactly as in the eager calls
+    assert torch.equal(s0.obs, s1.obs) and torch.equal(s0.done, s1.done) and torch.equal(s0.reward, s1.reward)
+    for k in ("steps", "truncation", "traj", "cur_frame", "sub_clip_frame"):
+        assert torch.equal(s0.info[k], s1.info[k]), k
+    for n in s0.pipeline_state._FIELDS:
+        assert torch.equal(s0.pipeline_state.raw(n), s1.pipeline_state.raw(n)), n

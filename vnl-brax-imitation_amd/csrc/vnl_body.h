@@ -590,6 +590,17 @@ struct EnvWave {
     // reads were an L2 round trip in the middle of a serial chain
     VNL_FOR(i, m.nv) s[L.LD + madr(i)] += m.dof_armature[i] + diag_scale * m.dof_damping[i];
     VNL_SYNC();
+    if (m.solver_newton && diag_scale == vreal(0.)) {  // dense symmetric copy of qM: the Newton solver's Hessian and M * search
+      const int nv = m.nv;
+      VNL_FOR(k, nv * nv) s[L.newt_M + k] = vreal(0.);
+      VNL_SYNC();
+      VNL_FOR(e, m.nM) {
+        const int i = m.M_row[e], j = anc_of(e);
+        const vreal v = s[L.LD + e];
+        s[L.newt_M + i * nv + j] = v, s[L.newt_M + j * nv + i] = v;
+      }
+      VNL_SYNC();
+    }
     VNL_PROF(6);
   }
 
@@ -695,6 +706,7 @@ struct EnvWave {
   struct R4 {
     vreal x, y, z, w;
   };
+  typedef vreal v2r __attribute__((vector_size(2 * sizeof(vreal))));  // (system 1, system 2) of a substep's two factorisations
   VNL_HD static R4 ld4a(const vreal* p) {  // p is 16-byte aligned in the float build
 #if defined(__HIPCC__)
     if constexpr (sizeof(vreal) == 4) {
@@ -944,12 +956,12 @@ struct EnvWave {
   // Which published pivots row a must absorb in which step is static per model: m.fac_match[a][step] (one bit per
   // scratch line, host-made), read one step ahead -- no line headers, no per-step ancestor tests.
   template <int NSET, int MAXD, int MAXD1 = MAXD>
-  VNL_HD void factor_pair(vreal h, vreal* g2) const {
+  VNL_HD void factor_pair(vreal h) const {
     static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
     constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
     auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
     constexpr int LW = MAXD + 4;  // [row numerators (MAXD) | 1/pivot | pad]
-    vreal r1[NSET][MAXD], r2[NSET][MAXD], d1[NSET], d2[NSET], inv2[NSET];
+    vreal r1[NSET][MAXD], r2[NSET][MAXD], d1[NSET], d2[NSET], inv1[NSET], inv2[NSET];
     int dep[NSET], ftime[NSET], myline[NSET];
     const unsigned char* mt[NSET];
     const int sc = (L.Ma + 3) & ~3, sc2 = sc + VNL_FAC_LINES * LW;  // Ma .. tmp2 are dead while factorising
@@ -962,7 +974,7 @@ struct EnvWave {
       dep[q] = d;
       d1[q] = ok ? s[L.LD + adr] : vreal(1.);
       d2[q] = ok ? d1[q] + h * m.dof_damping[a] : vreal(1.);
-      inv2[q] = vreal(0.);
+      inv1[q] = inv2[q] = vreal(0.);
 #pragma unroll
       for (int c = 0; c < MAXD; c++)
         if (c < qd(q)) r1[q][c] = r2[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
@@ -996,8 +1008,7 @@ struct EnvWave {
           }
           const vreal i1 = vnl_recip(d1[q]), i2 = vnl_recip(d2[q]);
           s[l1 + MAXD] = i1, s[l2 + MAXD] = i2;
-          s[L.dinv + a] = i1;
-          inv2[q] = i2;
+          inv1[q] = i1, inv2[q] = i2;
         }
       }
       VNL_WAVE_FENCE();
@@ -1051,14 +1062,13 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      if (a < m.nv) {
-        int adr = madr(a), d = dep[q];
-        vreal di = s[L.dinv + a];
-        s[L.LD + adr] = d1[q];
-        g2[adr] = d2[q], g2[m.nM + a] = inv2[q];
+      if (a < m.nv) {  // the interleaved image mass_mul_pair / invert_pair read (see the packed form below)
+        const int adr = madr(a), d = dep[q], R2 = pair_base(), DV = pair_dinv();
+        s[R2 + 2 * adr] = d1[q], s[R2 + 2 * adr + 1] = d2[q];
+        s[DV + 2 * a] = inv1[q], s[DV + 2 * a + 1] = inv2[q];
 #pragma unroll
         for (int c = 0; c < MAXD; c++)
-          if (c < qd(q) && c < d) s[L.LD + adr + d - c] = r1[q][c] * di, g2[adr + d - c] = r2[q][c] * inv2[q];
+          if (c < qd(q) && c < d) s[R2 + 2 * (adr + d - c)] = r1[q][c] * inv1[q], s[R2 + 2 * (adr + d - c) + 1] = r2[q][c] * inv2[q];
       }
     }
     VNL_SYNC();
@@ -1075,9 +1085,8 @@ struct EnvWave {
   //    row is shallow (host table m.fac_guest: host depth <= 12, guest depth <= 24), in column chunks 1-2, which the deep
   //    rows of other lanes occupy anyway -- the guest's updates share those lanes' instructions, each lane reading ITS
   //    pivot line with ITS multiplier.
-  typedef vreal v2r __attribute__((vector_size(2 * sizeof(vreal))));
   template <int MAXD, bool GUESTS>
-  VNL_HD void factor_pair_packed(vreal h, vreal* g2) const {
+  VNL_HD void factor_pair_packed(vreal h) const {
     static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
     constexpr int CH = MAXD % 12 == 0 ? 12 : 16, NCH = MAXD / CH;
     static_assert(!GUESTS || NCH == 3, "guest rows sit in chunks 1-2 of 3");
@@ -1090,13 +1099,13 @@ struct EnvWave {
     const bool okA = a < m.nv, hasB = g >= 0;
     const int adrA = okA ? madr(a) : 0, depA = okA ? eadr(a) - adrA : 0;
     const int adrB = hasB ? madr(g) : 0, depB = hasB ? eadr(g) - adrB : 0;
-    v2r dgA, dgB, i2;  // diagonals of both systems; i2 = (1 / D2 of row A, of row B) once they were pivots
+    v2r dgA, dgB, ivA, ivB;  // diagonals of both systems; iv = their reciprocals once the row was a pivot
     {
       const vreal d1 = okA ? s[L.LD + adrA] : vreal(1.);
       dgA = v2r{d1, okA ? d1 + h * m.dof_damping[a] : vreal(1.)};
       const vreal e1 = hasB ? s[L.LD + adrB] : vreal(1.);
       dgB = v2r{e1, hasB ? e1 + h * m.dof_damping[hasB ? g : 0] : vreal(1.)};
-      i2 = v2r{vreal(0.), vreal(0.)};
+      ivA = ivB = v2r{vreal(0.), vreal(0.)};
     }
 #pragma unroll
     for (int c = 0; c < MAXD; c++) {
@@ -1132,16 +1141,12 @@ struct EnvWave {
           }
         }
         if (pubA) {
-          const vreal i1 = vnl_recip(dgA[0]), j2 = vnl_recip(dgA[1]);
-          s[lA + 2 * MAXD] = i1, s[lA + 2 * MAXD + 1] = j2;
-          s[L.dinv + a] = i1;
-          i2[0] = j2;
+          ivA = v2r{vnl_recip(dgA[0]), vnl_recip(dgA[1])};
+          s[lA + 2 * MAXD] = ivA[0], s[lA + 2 * MAXD + 1] = ivA[1];
         }
         if (pubB) {
-          const vreal i1 = vnl_recip(dgB[0]), j2 = vnl_recip(dgB[1]);
-          s[lB + 2 * MAXD] = i1, s[lB + 2 * MAXD + 1] = j2;
-          s[L.dinv + g] = i1;
-          i2[1] = j2;
+          ivB = v2r{vnl_recip(dgB[0]), vnl_recip(dgB[1])};
+          s[lB + 2 * MAXD] = ivB[0], s[lB + 2 * MAXD + 1] = ivB[1];
         }
       }
       VNL_WAVE_FENCE();
@@ -1201,22 +1206,28 @@ struct EnvWave {
     }
     VNL_SYNC();
     VNL_PROF(8);
-    // system 1 -> L.LD / L.dinv (unit-lower rows scaled by 1/D), system 2 -> the env's global scratch (euler())
+    // both factors leave as ONE interleaved image: (L1, L2) entry pairs (unit-lower rows scaled by 1/D) from pair_base() on,
+    // the pairs of reciprocal pivots at pair_dinv() -- mass_mul_pair and invert_pair read them there
+    const int R2 = pair_base(), DV = pair_dinv();
     if (okA) {
-      const vreal di = s[L.dinv + a];
-      s[L.LD + adrA] = dgA[0];
-      g2[adrA] = dgA[1], g2[m.nM + a] = i2[0];
+      s[R2 + 2 * adrA] = dgA[0], s[R2 + 2 * adrA + 1] = dgA[1];
+      s[DV + 2 * a] = ivA[0], s[DV + 2 * a + 1] = ivA[1];
 #pragma unroll
       for (int c = 0; c < MAXD; c++)
-        if (c < depA && !(GUESTS && hasB && c >= CH)) s[L.LD + adrA + depA - c] = rr[c][0] * di, g2[adrA + depA - c] = rr[c][1] * i2[0];
+        if (c < depA && !(GUESTS && hasB && c >= CH)) {
+          const v2r v = rr[c] * ivA;
+          s[R2 + 2 * (adrA + depA - c)] = v[0], s[R2 + 2 * (adrA + depA - c) + 1] = v[1];
+        }
     }
     if (GUESTS && hasB) {
-      const vreal di = s[L.dinv + g];
-      s[L.LD + adrB] = dgB[0];
-      g2[adrB] = dgB[1], g2[m.nM + g] = i2[1];
+      s[R2 + 2 * adrB] = dgB[0], s[R2 + 2 * adrB + 1] = dgB[1];
+      s[DV + 2 * g] = ivB[0], s[DV + 2 * g + 1] = ivB[1];
 #pragma unroll
       for (int c = CH; c < MAXD; c++)
-        if (c - CH < depB) s[L.LD + adrB + depB - (c - CH)] = rr[c][0] * di, g2[adrB + depB - (c - CH)] = rr[c][1] * i2[1];
+        if (c - CH < depB) {
+          const v2r v = rr[c] * ivB;
+          s[R2 + 2 * (adrB + depB - (c - CH))] = v[0], s[R2 + 2 * (adrB + depB - (c - CH)) + 1] = v[1];
+        }
     }
     VNL_SYNC();
     VNL_PROF(9);
@@ -1232,18 +1243,19 @@ struct EnvWave {
                       (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16 && m.fac_guest);
     // (m.fac_guest: the rows 64.. have a place in the packed device form; a model where they have none takes the
     // one-system route in both builds, so that the two forms of factor_pair always run on the same models)
-    return regs && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
+    // .. and the interleaved image of both factors (2 nM elements from L.LD on) ends below cvel, which make_constraint still needs
+    return regs && 2 * m.nM <= L.pair_room && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
   }
-  VNL_HD void factor_both(vreal h, vreal* g2) const {
+  VNL_HD void factor_both(vreal h) const {
     const int nv = m.nv, md = m.max_depth;
 #ifdef VNL_FAC_PACKED
-    if (nv <= VNL_LANES && md < 16) return factor_pair_packed<16, false>(h, g2);
-    if (nv <= VNL_LANES) return factor_pair_packed<36, false>(h, g2);
-    return factor_pair_packed<36, true>(h, g2);  // (factor_pair_ok(): the guests could be placed)
+    if (nv <= VNL_LANES && md < 16) return factor_pair_packed<16, false>(h);
+    if (nv <= VNL_LANES) return factor_pair_packed<36, false>(h);
+    return factor_pair_packed<36, true>(h);  // (factor_pair_ok(): the guests could be placed)
 #else
-    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_pair<VNL_ROWSETS_1, 16>(h, g2);
-    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) factor_pair<VNL_ROWSETS_1, 36>(h, g2);
-    else factor_pair<VNL_ROWSETS_2, 36, 16>(h, g2);
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_pair<VNL_ROWSETS_1, 16>(h);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) factor_pair<VNL_ROWSETS_1, 36>(h);
+    else factor_pair<VNL_ROWSETS_2, 36, 16>(h);
 #endif
   }
 
@@ -1282,9 +1294,11 @@ struct EnvWave {
   VNL_HD void invert_factor() const { invert_factor(L.LD); }
 
   // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
+  // (ST: element stride of the factor -- 1, or 2 for system 1 of the interleaved pair that factor_pair leaves)
+  template <int ST = 1>
   VNL_HD vreal row_dot(int adr, int dep, int in, int LDb) const {
     const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
-    const vreal* row = s + LDb + adr;
+    const vreal* row = s + LDb + ST * adr;
     vreal acc = vreal(0.);
     int t = 1;
     constexpr int W = VNL_CHAIN_WIDTH;  // independent index->value chains per trip: two LDS round trips per trip
@@ -1294,7 +1308,7 @@ struct EnvWave {
 #pragma unroll
       for (int u = 0; u < W; u++) j[u] = an[t + u];
 #pragma unroll
-      for (int u = 0; u < W; u++) l[u] = row[t + u];
+      for (int u = 0; u < W; u++) l[u] = row[ST * (t + u)];
 #pragma unroll
       for (int u = 0; u < W; u++) x[u] = s[in + j[u]];
       vreal p0 = vreal(0.), p1 = vreal(0.);
@@ -1308,7 +1322,7 @@ struct EnvWave {
 #pragma unroll
       for (int u = 0; u < W; u++) {
         const int tt = t + u <= dep ? t + u : dep;
-        j[u] = an[tt], l[u] = row[tt];
+        j[u] = an[tt], l[u] = row[ST * tt];
       }
 #pragma unroll
       for (int u = 0; u < W; u++) x[u] = s[in + j[u]];
@@ -1333,12 +1347,13 @@ struct EnvWave {
     VNL_SYNC();
   }
   // out[a] = (in[a] + sum_{i in desc(a)} A(i, a) in[i]) (* or / D); descendants are the next ndesc dofs
+  template <int ST = 1>
   VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/, int LDb, int dinvb) const {
     VNL_FOR(a, m.nv) {
       int da = eadr(a) - madr(a), nd = ndesc(a);
       vreal acc = s[in + a];
       const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
-      const vreal* ld = s + LDb - da;
+      const vreal* ld = s + LDb - ST * da;
       int i = a + 1, iend = a + nd;
       constexpr int W = VNL_CHAIN_WIDTH;
       for (; i + W - 1 <= iend; i += W) {
@@ -1349,7 +1364,7 @@ struct EnvWave {
 #pragma unroll
         for (int u = 0; u < W; u++) x[u] = s[in + i + u];
 #pragma unroll
-        for (int u = 0; u < W; u++) l[u] = ld[e[u]];
+        for (int u = 0; u < W; u++) l[u] = ld[ST * e[u]];
         vreal p0 = vreal(0.), p1 = vreal(0.);
 #pragma unroll
         for (int u = 0; u < W; u += 2) p0 += l[u] * x[u], p1 += l[u + 1] * x[u + 1];
@@ -1364,7 +1379,7 @@ struct EnvWave {
           e[u] = ea[ii], x[u] = s[in + ii];
         }
 #pragma unroll
-        for (int u = 0; u < W; u++) l[u] = ld[e[u]];
+        for (int u = 0; u < W; u++) l[u] = ld[ST * e[u]];
         vreal p0 = vreal(0.), p1 = vreal(0.);
 #pragma unroll
         for (int u = 0; u < W; u += 2) {
@@ -1373,7 +1388,7 @@ struct EnvWave {
         }
         acc += p0 + p1;
       }
-      s[out + a] = dmode == 1 ? acc * s[dinvb + a] : (dmode == 2 ? acc / s[dinvb + a] : acc);
+      s[out + a] = dmode == 1 ? acc * s[dinvb + ST * a] : (dmode == 2 ? acc / s[dinvb + ST * a] : acc);
     }
     VNL_SYNC();
   }
@@ -1395,6 +1410,84 @@ struct EnvWave {
     VNL_SYNC();
     col_apply(L.tmp2, out, 0, L.LD, L.dinv);
   }
+
+  // out = M v from system 1 of the INTERLEAVED pair factor_pair leaves: (L1, L2) entry pairs at R2 + 2 k, (1/D1, 1/D2) at DV + 2 a
+  VNL_HD void mass_mul_pair(int vec, int out, int R2, int DV) const {
+    VNL_FOR(i, m.nv) {
+      int adr = madr(i), dep = eadr(i) - adr;
+      vreal acc = s[vec + i] + row_dot<2>(adr, dep, vec, R2);
+      s[L.tmp2 + i] = acc / s[DV + 2 * i];
+    }
+    VNL_SYNC();
+    col_apply<2>(L.tmp2, out, 0, R2, DV);
+  }
+
+  // BOTH factors of a substep inverted in ONE pass (same recursion as invert_rows, the two systems side by side: one packed
+  // multiply-add and one 8-byte LDS read per entry pair instead of two inversions -- the second one used to run in euler()).
+  // In: the interleaved pair at R2 / DV.  Out: N1 = L1^-1 in L.LD and 1/D1 in L.dinv, as every M^-1 product expects them;
+  // N2 and 1/D2 in the env's global scratch g2 [nM + nv], which euler() brings back once the solver has released the pool.
+  // All reads come before the one barrier, all writes after it (the outputs overlap the interleaved input).
+  template <int NSET, int MAXD, int MAXD1 = MAXD>
+  VNL_HD void invert_pair(int R2, int DV, vreal* g2) const {
+    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
+    v2r nn[NSET][MAXD], dg[NSET];
+    int adrs[NSET], deps[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      const int a = (int)lane + q * VNL_LANES;
+      const bool ok = a < m.nv;
+      const int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
+      adrs[q] = adr, deps[q] = d;
+      const vreal* own = s + R2 + 2 * adr;
+      dg[q] = v2r{own[0], own[1]};
+      const vreal* pb[MAXD];  // pair row of the u-th ancestor (rows past the depth alias row 0: read, never used)
+#pragma unroll
+      for (int u = 1; u < MAXD; u++)
+        if (u < qd(q)) pb[u] = s + R2 + 2 * (u < d ? madr(anc_of(adr + u)) : 0);
+#pragma unroll
+      for (int t = 1; t < MAXD; t++) {
+        if (t < qd(q) && vnl_wave_any(t <= d)) {
+          v2r x[MAXD];  // all operands of entry t are fetched before the (dependent) multiply-add chain
+#pragma unroll
+          for (int u = 1; u < t; u++) x[u] = v2r{pb[u][2 * (t - u)], pb[u][2 * (t - u) + 1]};
+          v2r acc = t <= d ? v2r{-own[2 * t], -own[2 * t + 1]} : v2r{vreal(0.), vreal(0.)};
+#pragma unroll
+          for (int u = 1; u < t; u++) acc -= nn[q][u] * x[u];
+          nn[q][t] = acc;
+        }
+      }
+    }
+    v2r dv[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      const int a = (int)lane + q * VNL_LANES;
+      dv[q] = a < m.nv ? v2r{s[DV + 2 * a], s[DV + 2 * a + 1]} : v2r{vreal(0.), vreal(0.)};
+    }
+    VNL_SYNC();
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      const int a = (int)lane + q * VNL_LANES;
+      if (a < m.nv) {
+        const int adr = adrs[q], d = deps[q];
+        s[L.LD + adr] = dg[q][0], g2[adr] = dg[q][1];
+        s[L.dinv + a] = dv[q][0], g2[m.nM + a] = dv[q][1];
+#pragma unroll
+        for (int t = 1; t < MAXD; t++)
+          if (t < qd(q) && t <= d) s[L.LD + adr + t] = nn[q][t][0], g2[adr + t] = nn[q][t][1];
+      }
+    }
+    VNL_SYNC();
+  }
+  VNL_HD void invert_both(int R2, int DV, vreal* g2) const {
+    const int nv = m.nv, md = m.max_depth;
+    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_pair<VNL_ROWSETS_1, 16>(R2, DV, g2);
+    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) invert_pair<VNL_ROWSETS_1, 36>(R2, DV, g2);
+    else invert_pair<VNL_ROWSETS_2, 36, 16>(R2, DV, g2);
+  }
+  // where factor_pair leaves the interleaved pair: from L.LD on (through L.dinv into the pool, below cvel), and the pair of
+  // reciprocal pivots in the first two of the eight CG vectors (dead until the solver starts)
+  VNL_HD int pair_base() const { return L.LD; }
+  VNL_HD int pair_dinv() const { return L.Ma; }
 
   // ------------------------------------------------------------------ velocity
   // com_vel + rne: -qfrc_bias - damping*qvel -> L.smooth.  Body velocities / accelerations are tree prefixes
@@ -1920,7 +2013,89 @@ struct EnvWave {
       return accepted;
   }
 
-  // solver.solve (CG).  One env per wave: the while loops run with this env's own trip counts.
+  // ---- Newton solver (solver.py _update_gradient, SolverType.NEWTON): Mgrad = H^-1 grad with the Hessian of the cost at the
+  // current active set, H = qM + J' diag(efc_D * active) J -- formed and Cholesky-factorised dense in LDS (small models: the
+  // reference selects it for the ant, nv 14, configs/env_config.yaml:16-21).  efc_J is materialised once per substep.
+  VNL_HD void newton_jacobian() const {
+    const int nv = m.nv;
+    V3 n = v3(m.pnx, m.pny, m.pnz);
+    VNL_FOR(k, m.nefc * nv) s[L.newt_J + k] = vreal(0.);
+    VNL_SYNC();
+    VNL_FOR(r, m.nlimit) s[L.newt_J + r * nv + m.lim_dof[r]] = copysign(vreal(1.), s[L.efc_D + r]);
+    VNL_FOR(q, m.ncon * nv) {
+      const int c = q / nv, d = q - c * nv, g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
+      if (s[L.efc_D + r0] == vreal(0.)) continue;
+      const int* seg = m.body_pathseg + 8 * con_body(c);
+      bool on_path = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) on_path = on_path || (d >= (seg[k] & 0xff) && d < (seg[k] >> 8));
+      if (!on_path) continue;
+      const S6 cd = ld6(L.cdof + 6 * d);
+      const V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
+      const V3 pv = cd.l + cross(cd.a, rel);
+      const vreal mu = m.cg_mu[g], jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
+      s[L.newt_J + r0 * nv + d] = jn + j1, s[L.newt_J + (r0 + 1) * nv + d] = jn - j1;
+      s[L.newt_J + (r0 + 2) * nv + d] = jn + j2, s[L.newt_J + (r0 + 3) * nv + d] = jn - j2;
+    }
+    VNL_SYNC();
+  }
+  // x <- H^-1 x (x: a dof vector in LDS); Jaref as it stands decides the active set
+  VNL_HD void newton_solve(int x) const {
+    const int nv = m.nv, H = L.newt_H;
+    VNL_FOR(k, nv * nv) {
+      const int i = k / nv, j = k - i * nv;
+      vreal h = s[L.newt_M + k];
+      for (int r = 0; r < m.nefc; r++) {
+        const vreal D = s[L.efc_D + r];
+        if (D != vreal(0.) && s[L.Jaref + r] < vreal(0.)) h += fabs(D) * s[L.newt_J + r * nv + i] * s[L.newt_J + r * nv + j];
+      }
+      s[H + k] = h;
+    }
+    VNL_SYNC();
+    // dense Cholesky, lower, column by column (cho_factor): the diagonal by one lane, the column below it one row per lane
+    for (int j = 0; j < nv; j++) {
+      VNL_SERIAL {
+        vreal d = s[H + j * nv + j];
+        for (int k = 0; k < j; k++) d -= s[H + j * nv + k] * s[H + j * nv + k];
+        if (!(d > vreal(0.))) d = VNL_MINVAL;
+        s[H + j * nv + j] = sqrt(d);
+      }
+      VNL_SYNC();
+      VNL_FOR(i, nv) {
+        if (i > j) {
+          vreal t = s[H + i * nv + j];
+          for (int k = 0; k < j; k++) t -= s[H + i * nv + k] * s[H + j * nv + k];
+          s[H + i * nv + j] = t / s[H + j * nv + j];
+        }
+      }
+      VNL_SYNC();
+    }
+    VNL_SERIAL {  // cho_solve: forward and back substitution
+      for (int i = 0; i < nv; i++) {
+        vreal v = s[x + i];
+        for (int k = 0; k < i; k++) v -= s[H + i * nv + k] * s[x + k];
+        s[x + i] = v / s[H + i * nv + i];
+      }
+      for (int i = nv - 1; i >= 0; i--) {
+        vreal v = s[x + i];
+        for (int k = i + 1; k < nv; k++) v -= s[H + k * nv + i] * s[x + k];
+        s[x + i] = v / s[H + i * nv + i];
+      }
+    }
+    VNL_SYNC();
+  }
+  // out = qM v (dense copy): with search = -H^-1 grad the recurrence M s' = -grad + beta M s of the CG route does not hold
+  VNL_HD void newton_mass_mul(int v, int out) const {
+    const int nv = m.nv;
+    VNL_FOR(i, nv) {
+      vreal acc = vreal(0.);
+      for (int j = 0; j < nv; j++) acc += s[L.newt_M + i * nv + j] * s[v + j];
+      s[out + i] = acc;
+    }
+    VNL_SYNC();
+  }
+
+  // solver.solve (CG / Newton).  One env per wave: the while loops run with this env's own trip counts.
   VNL_HD void solve() const {
     const int nv = m.nv, ne = m.nefc;
     // --- warm start selection: cost at qacc_warmstart vs qacc_smooth.
@@ -1961,15 +2136,22 @@ struct EnvWave {
     }
     gg = vnl_wave_sum(gg);
     VNL_SYNC();
-    fresh().solve_inplace(L.Mgrad);
+    const bool newton = m.solver_newton != 0;
+    if (newton) {
+      fresh().newton_jacobian();
+      fresh().newton_solve(L.Mgrad);
+    } else {
+      fresh().solve_inplace(L.Mgrad);
+    }
     VNL_FOR(d, nv) {
       const vreal mg = s[L.Mgrad + d], gr = s[L.grad + d];
       s[L.search + d] = -mg;
-      s[L.mv + d] = -gr;  // M search
+      s[L.mv + d] = -gr;  // M search (CG: search = -M^-1 grad)
       ss += mg * mg, gp += gr * mg;
     }
     ss = vnl_wave_sum(ss), gp = vnl_wave_sum(gp);
     VNL_SYNC();
+    if (newton) fresh().newton_mass_mul(L.search, L.mv);
     VNL_PROF(15);
 
     for (int it = 0; it < m.iterations; it++) {
@@ -2026,10 +2208,12 @@ struct EnvWave {
       d1 = vnl_wave_sum(d1), gg = vnl_wave_sum(gg);
       VNL_SYNC();
       VNL_PROF(23);
-      fresh().solve_inplace(L.tmp);
+      if (newton) fresh().newton_solve(L.tmp);
+      else fresh().solve_inplace(L.tmp);
       VNL_PROF(24);
       vreal d2 = vdot(L.grad, L.tmp);
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
+      if (newton) beta = vreal(0.);  // solver.solve: search = -Mgrad
       gp = d2;  // grad . Mgrad with Mgrad := tmp below
       ss = vreal(0.);
       VNL_FOR(d, nv) {
@@ -2042,6 +2226,7 @@ struct EnvWave {
       }
       ss = vnl_wave_sum(ss);
       VNL_SYNC();
+      if (newton) fresh().newton_mass_mul(L.search, L.mv);
       VNL_PROF(25);
     }
   }
@@ -2087,12 +2272,19 @@ struct EnvWave {
         kinematics();
         body_inertias(false);
         mass_matrix(vreal(0.));
-        if (factor_pair_ok()) factor_both(m.dt, fac2());
-      } else if (m.dbg_stage == 16) {  // euler()'s second-factor route: reload, invert in the pool, apply
+        if (factor_pair_ok()) factor_both(m.dt);
+      } else if (m.dbg_stage == 17) {
+        kinematics();
+        body_inertias(false);
+        mass_matrix(vreal(0.));
+        if (factor_pair_ok()) {
+          factor_both(m.dt);
+          invert_both(pair_base(), pair_dinv(), fac2());
+        }
+      } else if (m.dbg_stage == 16) {  // euler()'s second-factor route: reload, apply
         const vreal* g2 = fac2();
         VNL_FOR(k, m.nM + m.nv) s[L.P + k] = g2[k];
         VNL_SYNC();
-        invert_factor(L.P);
         solve_inplace(L.tmp, L.P, L.P + m.nM);
       } else if (m.dbg_stage == 18) {
         tree_accumulate(L.P, 10);
@@ -2107,11 +2299,17 @@ struct EnvWave {
     VNL_PROF(1);
     int cvel = fresh().bias_forces();
     fresh().mass_matrix(vreal(0.));
-    if (factor_pair_ok()) fresh().factor_both(m.dt, fac2());
-    else fresh().factor();
-    fresh().mass_mul_factor(L.qacc, L.mv);  // M * qacc_warmstart, needs L (before it becomes L^-1)
-    VNL_PROF(10);
-    fresh().invert_factor();
+    if (factor_pair_ok()) {
+      fresh().factor_both(m.dt);
+      fresh().mass_mul_pair(L.qacc, L.mv, pair_base(), pair_dinv());  // M * qacc_warmstart, needs L (before it becomes L^-1)
+      VNL_PROF(10);
+      fresh().invert_both(pair_base(), pair_dinv(), fac2());
+    } else {
+      fresh().factor();
+      fresh().mass_mul_factor(L.qacc, L.mv);
+      VNL_PROF(10);
+      fresh().invert_factor();
+    }
     VNL_PROF(11);
     fresh().smooth_forces();
     VNL_PROF(12);
@@ -2162,13 +2360,12 @@ struct EnvWave {
     VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
     VNL_SYNC();
     if (m.eulerdamp && factor_pair_ok()) {
-      // the factor of M + h diag(damping) was made next to M's by forward() (factor_pair): bring it into the pool
-      // (the constraint rows are dead now), invert it there and apply it
+      // the INVERTED factor of M + h diag(damping) was made beside M's by forward() (factor_pair + invert_pair): bring it
+      // into the pool (the constraint rows are dead now) and apply it
       const vreal* g2 = fac2();
       const int n2 = m.nM + m.nv;
       VNL_FOR(k, n2) s[L.P + k] = g2[k];
       VNL_SYNC();
-      fresh().invert_factor(L.P);
       fresh().solve_inplace(L.tmp, L.P, L.P + m.nM);
       VNL_PROF(27);
     } else if (m.eulerdamp) {

@@ -91,10 +91,6 @@ extern "C" int vnl_model_create(const void* blob, size_t nbytes, vnl_model** out
       delete m;
       return fail(VNL_ERR_BLOB, "blob lacks scalar %s", k);
     }
-  if (m->scalar("solver_newton") != 0) {
-    delete m;
-    return fail(VNL_ERR_UNSUPPORTED, "only the CG solver is implemented (reference envs/rodent.py:57-60 selects cg)");
-  }
   *out = m;
   return VNL_OK;
 }
@@ -157,6 +153,10 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   d.ncg = (int)S("ncg"), d.ncon = (int)S("ncon"), d.nlimit = (int)S("nlimit"), d.nefc = (int)S("nefc");
   d.iterations = (int)S("iterations"), d.ls_iterations = (int)S("ls_iterations"), d.eulerdamp = (int)S("eulerdamp");
   d.dt = (vreal)S("timestep"), d.tolerance = (vreal)S("tolerance"), d.ls_tolerance = (vreal)S("ls_tolerance");
+  d.solver_newton = S("solver_newton") != 0 ? 1 : 0;
+  // Newton (reference configs/env_config.yaml:16-21, the ant): the Hessian M + J' D J is formed and factorised DENSE in LDS
+  if (d.solver_newton && (d.nv > 48 || d.nefc > 160))
+    return fail(VNL_ERR_UNSUPPORTED, "the Newton solver is implemented for small models (nv <= 48, nefc <= 160): dense Hessian in LDS");
   d.dbg_stage = 0, d.dbg_count = 0;
 #ifdef VNL_STAGE_KNOBS  // diagnostic library only: the product library reads no environment variables
   if (const char* dbg = getenv("VNL_DBG_REPEAT")) sscanf(dbg, "%d:%d", &d.dbg_stage, &d.dbg_count);
@@ -530,6 +530,7 @@ static void layout(vnl_env* env) {
   if (d.eulerdamp) pool = imax(pool, d.nM + d.nv);  // euler() brings the second factor of the substep back into the pool
   L.P = sec("pool", pool);
   L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
+  L.pair_room = (L.P + 16 * d.nbody) - L.LD;  // bias_forces keeps cvel at pool + 16 nbody until make_constraint has read it
   env->sections["efc_D"] = {L.efc_D, d.nefc}, env->sections["Jaref"] = {L.Jaref, d.nefc};
   env->sections["jv"] = {L.jv, d.nefc};
   L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv), L.qacc = sec("qacc", d.nv);
@@ -541,6 +542,11 @@ static void layout(vnl_env* env) {
   L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
   L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
   L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 8 + 2 * VNL_LIVE_MAX));  // active contacts | their count | existing rows: count, list
+  L.newt_M = L.newt_H = L.newt_J = 0;
+  if (d.solver_newton) {
+    L.newt_M = sec("newton_qM", d.nv * d.nv), L.newt_H = sec("newton_H", d.nv * d.nv);
+    L.newt_J = sec("newton_efc_J", d.nefc * d.nv);
+  }
 #ifdef VNL_PROFILE
   o = (o + 1) & ~1;
   L.prof = sec("prof", 2 * (VNL_NPROF + 1));

@@ -34,6 +34,7 @@ typedef VNL_REAL vreal;
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
   int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds;
+  int solver_newton; /* opt.solver == NEWTON (reference configs/env_config.yaml:16-21): small models only (dense H in LDS) */
   int fac_steps; /* number of steps of the factorisation schedule */
   int fac_nleaf; /* low byte: leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand
                     side), else 0; bits 8..: depth of the deepest of the rows 64 .. (second lane set) */
@@ -109,6 +110,8 @@ struct WsLayout {
   int con_r, con_t1;    /* 3 per contact / 3 per collidable geom */
   int tab_anc, tab_madr, tab_body, tab_jump, tab_lvl; /* 8/16-bit index tables staged in LDS */
   int act_list;         /* ncon bytes: contacts with D != 0, then their count (int) */
+  int pair_room;        /* elements from LD to the part of the pool that stays live across the factorisation (cvel): room of the interleaved factor pair */
+  int newt_M, newt_H, newt_J; /* Newton solver only: dense qM (nv^2), Hessian / its Cholesky factor (nv^2), dense efc_J (nefc x nv) */
   int total;
 };
 

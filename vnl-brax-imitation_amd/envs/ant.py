@@ -46,11 +46,14 @@ class AntTracking(RodentTracking):
                  body_error_multiplier: float = 1.0, num_envs: int = 1, device: Any = "cuda", reference_clip=None,
                  model: Optional[_mjcf.CompiledModel] = None, mjcf_path: str = "./assets/ant.xml", **kwargs):
         params = dict(params or {})
-        if str(params.get("solver", "cg")).lower() == "newton":
-            warnings.warn("AntTracking: the Newton solver is not implemented; using CG with the same iteration counts")
+        solver = str(params.get("solver", "cg")).lower()  # ant.py:40-47; configs/env_config.yaml:16-21 selects newton, 1 / 4
         self.sys = model if model is not None else _load_model(
-            mjcf_path, None, "cg", int(params.get("iterations", 6)), int(params.get("ls_iterations", 6)))
+            mjcf_path, None, solver, int(params.get("iterations", 6)), int(params.get("ls_iterations", 6)))
         m = self.sys
+        if model is not None:  # a pre-compiled model: the env's params still decide the solver options, as in the reference
+            m.scalars.update(iterations=int(params.get("iterations", m.scalars["iterations"])),
+                             ls_iterations=int(params.get("ls_iterations", m.scalars["ls_iterations"])),
+                             solver_newton=1 if solver == "newton" else 0)
         m.scalars["eulerdamp"] = 0  # ant.py:47: mjDSBL_EULERDAMP
         self._n_frames = int(kwargs.get("n_frames", 5))  # ant.py:54-56
         self.backend = "mjx"

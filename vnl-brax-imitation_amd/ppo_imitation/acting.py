@@ -128,6 +128,77 @@ def _generate_unroll_fused(fz, env_state: State, policy, key, unroll_length: int
     return st, data
 
 
+class GraphedUnroll:
+    """acting.generate_unroll (reference acting.py:60-80) captured ONCE into a hipGraph and replayed: the `unroll_length`
+    policy launches, env step kernels, wrapper / logging launches and noise draws of an unroll are one graph launch instead
+    of ~11 launches per step issued from Python (the eager loop leaves ~0.13 ms of launch gaps and small copies per control
+    step on an MI355X).  Bit-identical to the eager fused unroll: same kernels, same arguments, same Philox stream
+    (tests/test_fused_rollout.py).
+
+    The graph works on fixed buffers: `env_state` (the env mutates it in place), the policy's parameter tensors (update them
+    IN PLACE between replays: the trainer's flat parameter buffer already is; a normaliser state must be copied into the one
+    given here) and the returned Transition, whose tensors are overwritten by the next replay.  `key` must be a generator
+    on the device; it is registered with the graph, so every replay continues its stream as eager calls would."""
+
+    def __init__(self, env, env_state: State, policy, key: torch.Generator, unroll_length: int,
+                 extra_fields: Sequence[str] = ()):
+        fz = _fusable(env)
+        dev = env_state.obs.device
+        if fz is None or dev.type != "cuda":
+            raise ValueError("GraphedUnroll needs AutoResetWrapper(EpisodeWrapper(<env on a HIP device>)), action_repeat 1")
+        if key is None or key.device.type != "cuda":
+            raise ValueError("GraphedUnroll needs a torch.Generator on the device (its stream is captured with the graph)")
+        self._args = (fz, env_state, policy, key, int(unroll_length), tuple(extra_fields))
+        self.state = env_state
+        # warm-up on a side stream (library handles, the policy's kernel object, allocator pools), with the generator and the
+        # env state put back afterwards: building the graph must not consume randomness or advance the envs
+        gen_state = key.get_state()
+        saved = _snapshot_state(env_state)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            _generate_unroll_fused(*self._args)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        _restore_state(env_state, saved)
+        key.set_state(gen_state)
+        self.graph = torch.cuda.CUDAGraph()
+        self.graph.register_generator_state(key)
+        with torch.cuda.graph(self.graph):
+            _, self.data = _generate_unroll_fused(*self._args)
+        self._hold = getattr(_generate_unroll_fused, "hold", None)
+        _restore_state(env_state, saved)  # (capture does not execute, but keep the contract explicit)
+
+    def __call__(self) -> Tuple[State, Transition]:
+        self.graph.replay()
+        return self.state, self.data
+
+
+def _state_tensors(st: State):
+    out = [st.pipeline_state.raw(n) for n in st.pipeline_state._FIELDS] + [st.obs, st.reward, st.done]
+    for k in sorted(st.info):
+        v = st.info[k]
+        if isinstance(v, torch.Tensor):
+            out.append(v)
+        elif isinstance(v, dict):
+            out += [v[k2] for k2 in sorted(v) if isinstance(v[k2], torch.Tensor)]
+    seen, uniq = set(), []
+    for t in out:  # (info["_raw"] aliases obs / reward / ...: each storage once)
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            uniq.append(t)
+    return uniq
+
+
+def _snapshot_state(st: State):
+    return [t.clone() for t in _state_tensors(st)]
+
+
+def _restore_state(st: State, saved) -> None:
+    for t, s in zip(_state_tensors(st), saved):
+        t.copy_(s)
+
+
 def generate_unroll(env, env_state: State, policy, key, unroll_length: int,
                     extra_fields: Sequence[str] = (), fused: Optional[bool] = None) -> Tuple[State, Transition]:
     """acting.py:60-80: Transitions stacked on a leading time axis [T, B, ...], written row by row into

@@ -380,15 +380,39 @@ def train(
                 acc[k] = acc.get(k, 0) + v
         return {k: v / num_minibatches for k, v in acc.items()}
 
+    graphed_roll: Dict[str, Any] = {}
+
+    def unroll_chunks(n_chunks: int):
+        """acting.generate_unroll x n_chunks (train.py:304-320).  With `capture_graph` on a HIP device the whole unroll is ONE
+        hipGraph replay (acting.GraphedUnroll): the policy reads the flat parameter buffer (updated in place by Adam) and a
+        static copy of the normaliser state, refreshed here before every replay."""
+        nonlocal env_state
+        use_graph = (capture_graph and device.type == "cuda" and g_dev is not g_env and acting._fusable(env) is not None)
+        if not use_graph:
+            policy = make_policy((training_state.normalizer_params, training_state.params.detach()[:n_pol]))
+            out = []
+            for _ in range(n_chunks):
+                env_state, data = acting.generate_unroll(env, env_state, policy, g_dev, unroll_length,
+                                                         extra_fields=("truncation", "traj"))
+                out.append(data)
+            return out
+        g = graphed_roll
+        if not g or g["unroll"].state is not env_state:  # (a fresh State after `env.reset`: the graph is bound to its buffers)
+            g["norm"] = training_state.normalizer_params.clone()
+            g["unroll"] = acting.GraphedUnroll(env, env_state, make_policy((g["norm"], training_state.params.detach()[:n_pol])),
+                                               g_dev, unroll_length, extra_fields=("truncation", "traj"))
+        for f in ("count", "mean", "summed_variance", "std"):
+            getattr(g["norm"], f).copy_(getattr(training_state.normalizer_params, f))
+        out = []
+        for k in range(n_chunks):
+            env_state, data = g["unroll"]()
+            out.append(data if n_chunks == 1 else data.map(torch.clone))  # the next replay overwrites the graph's buffers
+        return out
+
     def training_step() -> Metrics:
         """train.py:293-349."""
         nonlocal env_state
-        policy = make_policy((training_state.normalizer_params, training_state.params.detach()[:n_pol]))
-        chunks = []
-        for _ in range(batch_size * num_minibatches // num_envs):
-            env_state, data = acting.generate_unroll(env, env_state, policy, g_dev, unroll_length,
-                                                     extra_fields=("truncation", "traj"))
-            chunks.append(data)
+        chunks = unroll_chunks(batch_size * num_minibatches // num_envs)
         # [U, T, B, ...] -> swapaxes(1,2) -> reshape(-1, T, ...)   (train.py:323-327)
         data = chunks[0].map(lambda x: x) if len(chunks) == 1 else None
         if data is None:
