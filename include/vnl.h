@@ -306,6 +306,13 @@ int vnl_ppo_update_buffer(const vnl_ppo_update*, const char* name, float** dev_p
  * its (2T)^2 entries (reference intention_losses.py:186-188); 0 when 2T * B floats exceed 60 KB of LDS */
 int vnl_ppo_minibatch_grad(vnl_ppo_update*, const float* params, const vnl_ppo_batch*, const vnl_ppo_hparams*, float* grads,
                            float* metrics, void* stream);
+/* The same step in two parts, for data-parallel training (reference ppo_imitation/train.py:251-268 averages the gradient over the
+ * devices once per minibatch step): part 1 = forward of both networks + loss head + the VALUE network's backward -- in stream
+ * order the value segment grads[policy_params .. num_params) is then final; part 2 = the policy network's backward (same
+ * arguments, after part 1): the policy segment.  The caller all-reduces the value segment between the two, so that the
+ * exchange overlaps part 2.  part 0 = the whole step (== vnl_ppo_minibatch_grad). */
+int vnl_ppo_minibatch_grad_part(vnl_ppo_update*, const float* params, const vnl_ppo_batch*, const vnl_ppo_hparams*, float* grads,
+                                float* metrics, void* stream, int part);
 
 #ifdef __cplusplus
 }

@@ -24,11 +24,12 @@ def main():
     env = H.hostsim_env(4)  # per-rank shard of num_envs = 4 * world
     nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=8,
                            encoder_layer_sizes=(16,), decoder_layer_sizes=(16,), value_hidden_layer_sizes=(16,))
-    calls = {"allreduce": 0}
+    calls = {"allreduce": 0, "sizes": []}
     orig = dist.all_reduce
 
     def counting(t, *a, **k):
         calls["allreduce"] += 1
+        calls["sizes"].append(int(t.numel()))
         return orig(t, *a, **k)
 
     dist.all_reduce = counting
@@ -42,7 +43,9 @@ def main():
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     out = dict(rank=rank, identical=all(torch.equal(g, gathered[0]) for g in gathered), count=float(norm.count),
-               allreduce=calls["allreduce"], sps=metrics.get("training/sps", 0.0), nparam=int(flat.numel()))
+               allreduce=calls["allreduce"], sps=metrics.get("training/sps", 0.0), nparam=int(flat.numel()),
+               sizes=calls["sizes"], n_policy=int(ppo.train.last_ppo_network.policy_network.layout.size),
+               n_value=int(ppo.train.last_ppo_network.value_network.layout.size))
     print("RESULT " + json.dumps(out), flush=True)
     dist.destroy_process_group()
 

@@ -19,10 +19,16 @@ def test_two_rank_training_keeps_replicas_identical():
     import re
 
     # the two ranks write to one pipe: their lines may run together
-    res = [json.loads(m) for m in re.findall(r"RESULT (\{[^{}]*\})", p.stdout)]
+    res = [json.loads(m) for m in re.findall(r"RESULT (\{.*?\})(?=\s|RESULT|$)", p.stdout)]
     assert len(res) == 2
     for r in res:
         assert r["identical"]
         # normaliser saw the GLOBAL batch: 2 training steps x 8 envs x 4 steps
         assert r["count"] == 2 * 8 * 4
-        assert r["allreduce"] == 2 * (2 + 2 * 2)  # per training step: 2 normaliser + updates x minibatches gradient
+        # per training step: 2 normaliser all-reduces + per minibatch step TWO gradient all-reduces -- the value segment of
+        # the flat buffer first (final when the value chain has joined; its exchange overlaps the policy network's backward
+        # on a HIP device), then the policy segment -- each followed by Adam on that segment
+        assert r["allreduce"] == 2 * (2 + 2 * 2 * 2)
+        grad_sizes = [n for n in r["sizes"] if n in (r["n_value"], r["n_policy"])]
+        assert grad_sizes == [r["n_value"], r["n_policy"]] * (2 * 2 * 2), grad_sizes
+        assert r["n_value"] + r["n_policy"] == r["nparam"] or r["n_policy"] == r["nparam"]  # (params returned: the policy's)

@@ -133,3 +133,29 @@ def test_full_size_training_step_on_one_gpu():
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["env_steps"] == 2 * 4096 * 20 and np.isfinite(r["total_loss"]) and np.isfinite(r["v_loss"]) and r["training/sps"] > 0
     print(f"\n[full-size training step] {r['training/sps']:.0f} env-steps/s with 2 updates per batch (graph capture included)")
+
+
+def test_split_step_with_a_one_rank_process_group_matches_the_single_gpu_step():
+    """The data-parallel form of the minibatch step on the hardware that is there: a ONE-rank RCCL process group makes the
+    trainer take the split route -- graph 1 (gather, forward, head, value backward), all-reduce of the value segment on the
+    communication stream, graph 2 (policy backward) beside it, all-reduce of the policy segment, Adam per segment -- whose
+    result must agree with the unsplit single-GPU step (same seeds; the value network's output-layer gradient is summed in
+    another launch, so agreement is at rounding level, not bitwise)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    out = []
+    for extra in ([], ["--force-dist"]):
+        cmd = [sys.executable, os.path.join(H.ROOT, "tools", "train_bench.py"), "--steps", "2", "--updates", "2", "--backend", "hip",
+               "--envs-per-gpu", "512"] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_PORT="29713"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = out
+    print(f"\n[split step, one-rank RCCL group] total_loss {b['total_loss']:.6f} vs unsplit {a['total_loss']:.6f}; "
+          f"{b['training/sps']:.0f} vs {a['training/sps']:.0f} env-steps/s")
+    assert a["env_steps"] == b["env_steps"] and np.isfinite(b["total_loss"])
+    assert abs(a["total_loss"] - b["total_loss"]) <= 2e-3 * max(abs(a["total_loss"]), 1e-3), (a["total_loss"], b["total_loss"])
+    assert abs(a["v_loss"] - b["v_loss"]) <= 2e-3 * max(abs(a["v_loss"]), 1e-3)

@@ -48,9 +48,12 @@ def _product_step(env, c, idx):
     ps.raw("subtree_com1").copy_(torch.from_numpy(c["before_com1"][idx].astype(np.float32)))
     st.info["cur_frame"].copy_(torch.from_numpy(c["before_cur_frame"][idx]))
     st.info["sub_clip_frame"].copy_(torch.from_numpy(c["before_sub_clip_frame"][idx]))
+    env.debug(1)
     st = env.step(st, torch.from_numpy(c["action"][idx]))
+    trace = env.solver_trace().numpy().copy()
+    env.debug(0)
     ps = st.pipeline_state
-    return {k: P.to_np(getattr(ps, k)).astype(np.float64) for k in FIELDS}
+    return {k: P.to_np(getattr(ps, k)).astype(np.float64) for k in FIELDS}, trace
 
 
 def _natural(o64, o32, c, idx):
@@ -70,31 +73,66 @@ def _natural(o64, o32, c, idx):
     return n64, dev
 
 
+def _following(o64, o32, c, idx, nf, trace=None):
+    """float64 oracle FOLLOWING the recorded device decisions (or `trace`), its report, and the float32 following oracle's
+    sensitivity"""
+    act, tr = c["action"][idx], np.ascontiguousarray(c["trace"][idx][:, :nf] if trace is None else trace)
+    f64, _, rep = o64.env_step_follow(_oracle_state(o64, c, idx), act.astype(np.float64), tr)
+    dev = {k: np.zeros(len(idx)) for k in FIELDS}
+    rng = np.random.default_rng(12345)
+    for n in range(P.N_SENS):
+        t32 = _oracle_state(o32, c, idx)
+        if n > 0:
+            for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+                t32[k] = (t32[k] * (1 + np.float32(2.0 ** -23) * rng.integers(-1, 2, t32[k].shape).astype(np.float32))).astype(np.float32)
+        t32, _, _ = o32.env_step_follow(t32, act.astype(np.float32), tr)
+        for k in FIELDS:
+            dev[k] = np.maximum(dev[k], P.per_env_grouped(t32[k].astype(np.float64), f64[k], k))
+    return f64, dev, rep
+
+
 @pytest.mark.parametrize("n_frames", [1, 5])
 def test_recorded_cases_end_at_the_natural_oracles_minimiser(n_frames):
+    """Every recorded case must be explained ONE of two ways, per env and per output:
+      (A) the product is within its rounding bound of the NATURAL float64 oracle -- required whenever a followed decision was
+          NOT a tie for the oracle (the replay argument of DESIGN 2b: after a differing trial point the replayed bracket
+          decisions belong to other points), so that a non-tie decision is never what excuses an error; or
+      (B) every followed decision was a tie for the oracle (all three tie measures <= 1, the same rows active at every trial
+          step), and the product is within its rounding bound of the oracle FOLLOWING those decisions: it took the other side of
+          a genuine float32 tie (e.g. one CG iteration more: the result then moves by ~1e-3, in any float32 implementation); or,
+      (C) in the 5-substep cases only, as in parity.check_control_step: a LATER substep's decision flipped against the state
+          that had drifted apart by then (`drifted`), within FLIP_CAP."""
     c = _load()
     idx = np.where(c["n_frames"] == n_frames)[0]
     assert len(idx) >= 8
     env = H.hostsim_env(len(idx), "float", n_frames=n_frames)
     o64, o32 = H.make_oracle(env, "f64"), H.make_oracle(env, "f32")
     n64, dev = _natural(o64, o32, c, idx)
-    got = _product_step(env, c, idx)
+    got, host_trace = _product_step(env, c, idx)
     recorded = ~np.isnan(c["after_qvel"][idx]).any(axis=1)
     print(f"\n[{len(idx)} recorded cases, n_frames={n_frames}; device outputs kept for {int(recorded.sum())}]")
-    worst = {}
-    for who, out, rows in (("host build of the product source", got, np.ones(len(idx), bool)),
-                           ("device (recorded)", {k: c["after_" + k][idx].astype(np.float64) for k in FIELDS}, recorded)):
+    for who, out, rows, trace in (("host build of the product source", got, np.ones(len(idx), bool), host_trace),
+                                  ("device (recorded)", {k: c["after_" + k][idx].astype(np.float64) for k in FIELDS}, recorded, None)):
         if not rows.any():
             continue
+        f64, fdev, rep = _following(o64, o32, c, idx, n_frames, trace)
+        # route B: every followed decision a tie in the ORACLE's own judgement -- the followed step costs no more than its own
+        # within rounding, exit / warm-start choices on their thresholds, the same rows active at every trial step
+        faithful_tie = (~P.non_tie(rep)).all(axis=1)
+        flipped = P.drifted(rep) if n_frames > 1 else np.zeros(len(idx), bool)
         for k in FIELDS:
-            e = P.per_env_grouped(out[k][rows], n64[k][rows], k)
-            bound = np.maximum(P.TOL, P.K_SENS * dev[k][rows])
-            bad = np.where(e > bound)[0]
-            over = int((e > bound).sum())
-            worst[(who, k)] = (float(e.max()), float((e / bound).max()), over)
-            print(f"   {who:34s} {k:15s} max err {e.max():.2e}  worst err/bound {(e / bound).max():6.2f}  envs over their "
-                  f"rounding bound {over}")
-            assert len(bad) == 0, (who, k, idx[rows][bad][:8], e[bad][:8], bound[bad][:8], c["source"][idx[rows][bad]][:8])
+            e_nat = P.per_env_grouped(out[k][rows], n64[k][rows], k)
+            e_fol = P.per_env_grouped(out[k][rows], f64[k][rows], k)
+            ok_a = e_nat <= np.maximum(P.TOL, P.K_SENS * dev[k][rows])
+            ok_b = faithful_tie[rows] & (e_fol <= np.maximum(P.TOL, P.K_SENS * fdev[k][rows]))
+            ok_c = flipped[rows] & (np.minimum(e_nat, e_fol) <= P.FLIP_CAP)
+            bad = np.where(~(ok_a | ok_b | ok_c))[0]
+            print(f"   {who:34s} {k:15s} (A) within the natural oracle's bound {int(ok_a.sum())} of {len(ok_a)}; else (B) genuine ties "
+                  f"followed faithfully {int((~ok_a & ok_b).sum())}; else (C) a later substep's decision flipped {int((~ok_a & ~ok_b & ok_c).sum())}; "
+                  f"unexplained {len(bad)}")
+            assert len(bad) == 0, (who, k, idx[rows][bad][:8], e_nat[bad][:8], e_fol[bad][:8], c["source"][idx[rows][bad]][:8])
+            if n_frames == 1:  # single substeps: a decision that was not a tie is never what excuses an error (DESIGN 2b)
+                assert ok_a[~faithful_tie[rows]].all()
 
 
 def test_following_the_recorded_decisions_reproduces_the_recorded_report_and_faithful_replays_are_ties():

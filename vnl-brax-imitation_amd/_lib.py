@@ -140,6 +140,7 @@ EXPORTS = (
     "vnl_policy_num_params", "vnl_policy_forward", "vnl_rollout_post", "vnl_ppo_head", "vnl_adam_step", "vnl_gather_rows",
     "vnl_ppo_update_create", "vnl_ppo_update_destroy", "vnl_ppo_update_num_params", "vnl_ppo_update_buffer",
     "vnl_ppo_minibatch_grad",
+    "vnl_ppo_minibatch_grad_part",
 )
 _HIP_ONLY = ("vnl_policy_", "vnl_ppo_update_", "vnl_ppo_minibatch_")  # not in the test-only host simulation
 
@@ -176,6 +177,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
         lib.vnl_ppo_update_num_params.restype = C.c_int64
         lib.vnl_ppo_update_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int64)]
         lib.vnl_ppo_minibatch_grad.argtypes = [vp, vp, C.POINTER(PPOBatch), C.POINTER(PPOHParams), vp, vp, vp]
+        lib.vnl_ppo_minibatch_grad_part.argtypes = [vp, vp, C.POINTER(PPOBatch), C.POINTER(PPOHParams), vp, vp, vp, C.c_int]
     if hasattr(lib, "vnl_policy_create"):
         lib.vnl_policy_create.argtypes = [C.POINTER(PolicySpec), C.c_int32, C.c_int32, C.POINTER(vp)]
         lib.vnl_policy_destroy.argtypes = [vp]

@@ -1447,12 +1447,20 @@ struct EnvWave {
 #pragma unroll
       for (int t = 1; t < MAXD; t++) {
         if (t < qd(q) && vnl_wave_any(t <= d)) {
-          v2r x[MAXD];  // all operands of entry t are fetched before the (dependent) multiply-add chain
-#pragma unroll
-          for (int u = 1; u < t; u++) x[u] = v2r{pb[u][2 * (t - u)], pb[u][2 * (t - u) + 1]};
+          // the operands of entry t are fetched XB pairs at a time before their (dependent) multiply-add chain: all of
+          // them at once (invert_rows) would need 2 x 35 registers here
+          constexpr int XB = 12;
           v2r acc = t <= d ? v2r{-own[2 * t], -own[2 * t + 1]} : v2r{vreal(0.), vreal(0.)};
 #pragma unroll
-          for (int u = 1; u < t; u++) acc -= nn[q][u] * x[u];
+          for (int u0 = 1; u0 < t; u0 += XB) {
+            v2r x[XB];
+#pragma unroll
+            for (int u = u0; u < u0 + XB; u++)
+              if (u < t) x[u - u0] = v2r{pb[u][2 * (t - u)], pb[u][2 * (t - u) + 1]};
+#pragma unroll
+            for (int u = u0; u < u0 + XB; u++)
+              if (u < t) acc -= nn[q][u] * x[u - u0];
+          }
           nn[q][t] = acc;
         }
       }

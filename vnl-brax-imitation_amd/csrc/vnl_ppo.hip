@@ -901,6 +901,16 @@ static void ln_bwd(vnl_ppo_update* u, SlabPool* pool, hipStream_t st, const floa
 
 extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, const vnl_ppo_batch* bt, const vnl_ppo_hparams* hp,
                                       float* grads, float* metrics, void* stream) {
+  return vnl_ppo_minibatch_grad_part(u, params, bt, hp, grads, metrics, stream, 0);
+}
+
+/* part 0: the whole step.  part 1: forward of both networks, the loss head, the VALUE network's backward -- on return (in
+ * stream order) the value segment of `grads` [policy params .. end) is final.  part 2: the policy network's backward (after
+ * part 1 with the same arguments): the policy segment.  Data-parallel training issues the all-reduce of the value segment
+ * between the two, so that it overlaps part 2 (reference ppo_imitation/train.py:251-268: one pmean per minibatch step). */
+extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* params, const vnl_ppo_batch* bt,
+                                           const vnl_ppo_hparams* hp, float* grads, float* metrics, void* stream, int part) {
+  if (part < 0 || part > 2) return pfail(VNL_ERR_ARG, "vnl_ppo_minibatch_grad_part: part must be 0, 1 or 2");
   if (!u || !params || !bt || !hp || !grads || !metrics) return pfail(VNL_ERR_ARG, "vnl_ppo_minibatch_grad: null argument");
   const void* need[] = {bt->traj, bt->obs, bt->next_obs_last, bt->raw_action, bt->behaviour_log_prob, bt->reward, bt->truncation,
                         bt->discount, bt->eps_latent, bt->eps_entropy};
@@ -954,98 +964,108 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
   const float* P = params;
   float* Gr = grads;
 
-  // ---------------- forward
-  {
-    const size_t tot = (size_t)Nv * no + (size_t)N * u->ntp;
-    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256)), dim3(256), 0, st, bt->obs,
-                       bt->next_obs_last, bt->obs_mean, bt->obs_std, bt->traj, u->obsn, u->trajp, N, Nv, no, sp.traj_size, u->ntp);
-  }
-  PCHK(hipEventRecord(u->ev[0], st));
-  PCHK(hipStreamWaitEvent(sp2, u->ev[0], 0));
-  scope.forked = true;
-  // value MLP over the T*B rows + the B bootstrap rows (ppo_networks.py:114-118; swish)
   const int nvl = (int)u->val.size();  // hidden layers + the output layer
-  {
-    const float* x = u->obsn;
-    int ldx = no;
-    for (int i = 0; i + 1 < nvl; i++) {
-      const DenseP& d = u->val[i];
-      GV.run(false, false, EPI_SWISH, x, ldx, P + d.w, d.out, u->valA[i], d.out, Nv, d.out, d.in, P + d.b, nullptr, 0, u->valZ[i]);
-      x = u->valA[i], ldx = d.out;
+  if (part == 2) {  // the policy network's backward alone: fork the second stream from the caller's
+    PCHK(hipEventRecord(u->ev[0], st));
+    PCHK(hipStreamWaitEvent(sp2, u->ev[0], 0));
+    scope.forked = true;
+  } else {
+    // ---------------- forward
+    {
+      const size_t tot = (size_t)Nv * no + (size_t)N * u->ntp;
+      hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256)), dim3(256), 0, st, bt->obs,
+                         bt->next_obs_last, bt->obs_mean, bt->obs_std, bt->traj, u->obsn, u->trajp, N, Nv, no, sp.traj_size, u->ntp);
     }
-    const DenseP& d = u->val[nvl - 1];
-    hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
-  }
-  // encoder (intention_policy_network.py:20-44)
-  {
-    const float* x = u->trajp;
-    int ldx = u->ntp;
-    for (size_t i = 0; i < u->enc.size(); i++) {
-      const DenseP& d = u->enc[i];
-      GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->encH[i], d.out, N, d.out, d.in, P + d.b);
-      ln_fwd(sp2, u->encH[i], P + d.g, P + d.be, u->encY[i], u->encS[i], N, d.out);
-      x = u->encY[i], ldx = d.out;
+    PCHK(hipEventRecord(u->ev[0], st));
+    PCHK(hipStreamWaitEvent(sp2, u->ev[0], 0));
+    scope.forked = true;
+    // value MLP over the T*B rows + the B bootstrap rows (ppo_networks.py:114-118; swish)
+    {
+      const float* x = u->obsn;
+      int ldx = no;
+      for (int i = 0; i + 1 < nvl; i++) {
+        const DenseP& d = u->val[i];
+        GV.run(false, false, EPI_SWISH, x, ldx, P + d.w, d.out, u->valA[i], d.out, Nv, d.out, d.in, P + d.b, nullptr, 0, u->valZ[i]);
+        x = u->valA[i], ldx = d.out;
+      }
+      const DenseP& d = u->val[nvl - 1];
+      hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
     }
-    const int fan = u->enc.back().out;
-    GP.run(false, false, EPI_NONE, x, ldx, P + u->mean_w, lat, u->ml, 2 * lat, N, lat, fan, P + u->mean_b);
-    GP.run(false, false, EPI_NONE, x, ldx, P + u->lv_w, lat, u->ml + lat, 2 * lat, N, lat, fan, P + u->lv_b);
-    const size_t nz = (size_t)N * (lat + no);
-    hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, sp2, (const float*)u->ml, bt->eps_latent,
-                       (const float*)u->obsn, u->D0, N, lat, no);
-    hipLaunchKernelGGL(split_ml_kernel, dim3((N * lat + 255) / 256), dim3(256), 0, sp2, (const float*)u->ml, u->mean, u->logvar, N, lat);
-  }
-  // decoder (intention_policy_network.py:47-70)
-  {
-    const float* x = u->D0;
-    int ldx = lat + no;
-    for (size_t i = 0; i < u->dec.size(); i++) {
-      const DenseP& d = u->dec[i];
-      if (d.ln) {
-        GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->decH[i], d.out, N, d.out, d.in, P + d.b);
-        ln_fwd(sp2, u->decH[i], P + d.g, P + d.be, u->decY[i], u->decS[i], N, d.out);
-        x = u->decY[i], ldx = d.out;
-      } else {
-        GP.run(false, false, EPI_NONE, x, ldx, P + d.w, d.out, u->logits, d.out, N, d.out, d.in, P + d.b);
+    // encoder (intention_policy_network.py:20-44)
+    {
+      const float* x = u->trajp;
+      int ldx = u->ntp;
+      for (size_t i = 0; i < u->enc.size(); i++) {
+        const DenseP& d = u->enc[i];
+        GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->encH[i], d.out, N, d.out, d.in, P + d.b);
+        ln_fwd(sp2, u->encH[i], P + d.g, P + d.be, u->encY[i], u->encS[i], N, d.out);
+        x = u->encY[i], ldx = d.out;
+      }
+      const int fan = u->enc.back().out;
+      GP.run(false, false, EPI_NONE, x, ldx, P + u->mean_w, lat, u->ml, 2 * lat, N, lat, fan, P + u->mean_b);
+      GP.run(false, false, EPI_NONE, x, ldx, P + u->lv_w, lat, u->ml + lat, 2 * lat, N, lat, fan, P + u->lv_b);
+      const size_t nz = (size_t)N * (lat + no);
+      hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, sp2, (const float*)u->ml, bt->eps_latent,
+                         (const float*)u->obsn, u->D0, N, lat, no);
+      hipLaunchKernelGGL(split_ml_kernel, dim3((N * lat + 255) / 256), dim3(256), 0, sp2, (const float*)u->ml, u->mean, u->logvar, N, lat);
+    }
+    // decoder (intention_policy_network.py:47-70)
+    {
+      const float* x = u->D0;
+      int ldx = lat + no;
+      for (size_t i = 0; i < u->dec.size(); i++) {
+        const DenseP& d = u->dec[i];
+        if (d.ln) {
+          GP.run(false, false, EPI_RELU, x, ldx, P + d.w, d.out, u->decH[i], d.out, N, d.out, d.in, P + d.b);
+          ln_fwd(sp2, u->decH[i], P + d.g, P + d.be, u->decY[i], u->decS[i], N, d.out);
+          x = u->decY[i], ldx = d.out;
+        } else {
+          GP.run(false, false, EPI_NONE, x, ldx, P + d.w, d.out, u->logits, d.out, N, d.out, d.in, P + d.b);
+        }
       }
     }
+    PCHK(hipEventRecord(u->ev[1], sp2));
+    // ---------------- loss head: GAE, clipped surrogate, value / entropy / KL terms and d loss / d (network outputs)
+    {
+      vnl_ppo_head_args a{};
+      a.T = u->T, a.B = u->B, a.act = sp.action_size, a.latent = lat;
+      a.logits = u->logits, a.baseline = u->v, a.bootstrap = u->v + N, a.lat_mean = u->mean, a.lat_logvar = u->logvar;
+      a.raw_action = bt->raw_action, a.behaviour_log_prob = bt->behaviour_log_prob, a.reward = bt->reward;
+      a.truncation = bt->truncation, a.discount = bt->discount, a.eps_entropy = bt->eps_entropy;
+      a.entropy_cost = hp->entropy_cost, a.discounting = hp->discounting, a.reward_scaling = hp->reward_scaling;
+      a.gae_lambda = hp->gae_lambda, a.clipping_epsilon = hp->clipping_epsilon, a.kl_weight = hp->kl_weight;
+      a.min_std = hp->min_std, a.var_scale = hp->var_scale, a.normalize_advantage = hp->normalize_advantage;
+      a.g_logits = u->gl, a.g_baseline = u->gb, a.g_lat_mean = u->gklm, a.g_lat_logvar = u->gkll;
+      a.vs = u->vs, a.advantages = u->adv, a.metrics = metrics;
+      // GAE needs the value outputs only: it runs while the intention network's forward is still in flight
+      int rc = vnl_ppo_head_phase_(&a, u->headws, stream, 1);
+      if (rc != VNL_OK) return rc;
+      // metrics[8] = prediction_corr (a metric only), in the same slack; NaN ("not computed", never a fake 0.0) when the 2T
+      // rows do not fit in LDS -- the same rule as the torch backend (intention_losses.py: _corr_fits)
+      const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
+      if (lds <= 60 * 1024)
+        hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(VNL_CORR_THREADS), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
+                           u->T, u->B, metrics + 8);
+      else
+        PCHK(hipMemsetAsync(metrics + 8, 0xff, sizeof(float), st));  // 0xffffffff: a quiet NaN
+      PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
+      rc = vnl_ppo_head_phase_(&a, u->headws, stream, 2);
+      if (rc != VNL_OK) return rc;
+    }
   }
-  PCHK(hipEventRecord(u->ev[1], sp2));
-  // ---------------- loss head: GAE, clipped surrogate, value / entropy / KL terms and d loss / d (network outputs)
-  {
-    vnl_ppo_head_args a{};
-    a.T = u->T, a.B = u->B, a.act = sp.action_size, a.latent = lat;
-    a.logits = u->logits, a.baseline = u->v, a.bootstrap = u->v + N, a.lat_mean = u->mean, a.lat_logvar = u->logvar;
-    a.raw_action = bt->raw_action, a.behaviour_log_prob = bt->behaviour_log_prob, a.reward = bt->reward;
-    a.truncation = bt->truncation, a.discount = bt->discount, a.eps_entropy = bt->eps_entropy;
-    a.entropy_cost = hp->entropy_cost, a.discounting = hp->discounting, a.reward_scaling = hp->reward_scaling;
-    a.gae_lambda = hp->gae_lambda, a.clipping_epsilon = hp->clipping_epsilon, a.kl_weight = hp->kl_weight;
-    a.min_std = hp->min_std, a.var_scale = hp->var_scale, a.normalize_advantage = hp->normalize_advantage;
-    a.g_logits = u->gl, a.g_baseline = u->gb, a.g_lat_mean = u->gklm, a.g_lat_logvar = u->gkll;
-    a.vs = u->vs, a.advantages = u->adv, a.metrics = metrics;
-    // GAE needs the value outputs only: it runs while the intention network's forward is still in flight
-    int rc = vnl_ppo_head_phase_(&a, u->headws, stream, 1);
-    if (rc != VNL_OK) return rc;
-    // metrics[8] = prediction_corr (a metric only), in the same slack; NaN ("not computed", never a fake 0.0) when the 2T
-    // rows do not fit in LDS -- the same rule as the torch backend (intention_losses.py: _corr_fits)
-    const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
-    if (lds <= 60 * 1024)
-      hipLaunchKernelGGL(prediction_corr_kernel, dim3(1), dim3(VNL_CORR_THREADS), lds, st, (const float*)u->vs, bt->reward, hp->reward_scaling,
-                         u->T, u->B, metrics + 8);
-    else
-      PCHK(hipMemsetAsync(metrics + 8, 0xff, sizeof(float), st));  // 0xffffffff: a quiet NaN
-    PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
-    rc = vnl_ppo_head_phase_(&a, u->headws, stream, 2);
-    if (rc != VNL_OK) return rc;
+  if (part != 2) {
+    PCHK(hipEventRecord(u->ev[2], st));
+    PCHK(hipStreamWaitEvent(sp2, u->ev[2], 0));
   }
-  PCHK(hipEventRecord(u->ev[2], st));
-  PCHK(hipStreamWaitEvent(sp2, u->ev[2], 0));
   // ---------------- backward: value MLP (the bootstrap rows carry no gradient: stop_gradient, intention_losses.py:137)
-  {
+  if (part != 2) {
     const DenseP& dl = u->val[nvl - 1];
     const float* Alast = nvl >= 2 ? u->valA[nvl - 2] : u->obsn;
     // d w_out = A' gb, d b_out = sum gb: a 1025 x 1 product, 16 us as a launch of its own at the head of this chain -- it
     // joins the intention network's grouped weight-gradient launch on the other stream instead (operands ready since the head)
-    GP.wgrad(Alast, dl.in, u->gb, 1, Gr + dl.w, Gr + dl.b, dl.in, 1, N);
+    // (split step: it must be final with the rest of the value segment, so it takes a launch of its own on this stream)
+    if (part == 0) GP.wgrad(Alast, dl.in, u->gb, 1, Gr + dl.w, Gr + dl.b, dl.in, 1, N);
+    else GV.wgrad(Alast, dl.in, u->gb, 1, Gr + dl.w, Gr + dl.b, dl.in, 1, N);
     float *dz = u->dA, *dz_other = u->dB;
     if (nvl >= 2) {
       const int h = u->val[nvl - 2].out;
@@ -1064,7 +1084,7 @@ extern "C" int vnl_ppo_minibatch_grad(vnl_ppo_update* u, const float* params, co
     }
   }
   // ---------------- backward: decoder, latent, encoder (second stream)
-  {
+  if (part != 1) {
     // The chain of input gradients runs first, launch after launch; the layers' weight gradients [X | 1]' dZ are only
     // collected (GP.wgrad defers them) and run as one grouped launch at the end, so every dZ keeps a buffer of its own.
     float* dcur = u->dPa;     // d loss / d (a layer's input), consumed by the next launch

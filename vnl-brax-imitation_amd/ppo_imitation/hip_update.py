@@ -82,11 +82,13 @@ class HipPPOUpdate:
         return out
 
     def grad(self, params: torch.Tensor, normalizer_params, data: Transition, noise: Dict[str, torch.Tensor],
-             grads: torch.Tensor) -> torch.Tensor:
+             grads: torch.Tensor, part: int = 0) -> torch.Tensor:
         """`data`: TIME-MAJOR Transition [T, B, ...] (next_observation: at least its last row [.., B, obs]); `noise`:
         {"latent": [T,B,latent], "entropy": [T,B,act]} N(0,1) draws.  Writes d loss / d params into `grads` (flat, same
         layout) and returns the metrics tensor [9] (total, policy, value, entropy, KL losses, explained variance, advantage mean / std,
-        prediction_corr)."""
+        prediction_corr).  `part`: 0 = the whole step; 1 = forward + loss head + the value network's backward (the value
+        segment of `grads` is final afterwards), 2 = the policy network's backward (after part 1, same arguments): the
+        data-parallel trainer all-reduces the value segment between the two."""
         T, B = self.T, self.B
         assert params.is_contiguous() and grads.is_contiguous() and params.numel() == grads.numel() == self.num_params
         c = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
@@ -102,8 +104,8 @@ class HipPPOUpdate:
             keep += [c(normalizer_params.mean), c(normalizer_params.std)]
             b.obs_mean, b.obs_std = C.c_void_p(keep[-2].data_ptr()), C.c_void_p(keep[-1].data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self.lib, self.lib.vnl_ppo_minibatch_grad(self.h, C.c_void_p(params.data_ptr()), C.byref(b), C.byref(self.hp),
-                                                             C.c_void_p(grads.data_ptr()), C.c_void_p(self.metrics.data_ptr()),
-                                                             stream))
+        _lib.check(self.lib, self.lib.vnl_ppo_minibatch_grad_part(self.h, C.c_void_p(params.data_ptr()), C.byref(b), C.byref(self.hp),
+                                                                  C.c_void_p(grads.data_ptr()), C.c_void_p(self.metrics.data_ptr()),
+                                                                  stream, int(part)))
         self._hold = keep  # buffers of asynchronous launches
         return self.metrics

@@ -6,8 +6,9 @@ Same keyword signature and return triple `(make_policy, params, metrics)`; same 
 MI355X mapping of the reference's jax.pmap data parallelism (train.py:363):
   * one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI); `environment`
     is this rank's shard of the envs (its `num_envs` = per-rank envs);
-  * C1: gradients live in ONE flat float32 buffer (policy | value) -> one RCCL all-reduce per
-    minibatch step, averaged (brax gradient_update_fn pmean, train.py:251-253,264-266);
+  * C1: gradients live in ONE flat float32 buffer (policy | value), all-reduced (mean) per minibatch step in the two segments
+    it becomes final in -- value network first, overlapping the policy network's backward, then the policy's, each followed
+    by Adam on that segment (brax gradient_update_fn pmean, train.py:251-253,264-266: one pmean after the backward pass);
   * C2: normaliser statistics all-reduced once per training step (train.py:330-334);
   * C3: parameters broadcast from rank 0 at init (train.py:410-412);
   * C4: replicas are checked bit-identical at the end (train.py:485-487).
@@ -52,10 +53,18 @@ class FlatAdam:
                 "count": torch.zeros((), dtype=torch.int64, device=params.device)}
 
     @torch.no_grad()
-    def update(self, grads: torch.Tensor, state: Dict[str, torch.Tensor], params: torch.Tensor) -> None:
+    def update(self, grads: torch.Tensor, state: Dict[str, torch.Tensor], params: torch.Tensor,
+               segment: Optional[slice] = None, bump: bool = True) -> None:
         """No host read-back (the step count stays on the device), so the update can sit inside a hipGraph.
-        On a HIP device (or with `self.lib` set) the update itself is one launch of vnl_adam_step."""
-        state["count"] += 1
+        On a HIP device (or with `self.lib` set) the update itself is one launch of vnl_adam_step.
+        `segment`: update only that slice of the flat buffer (the data-parallel step updates the value segment as soon as its
+        all-reduce is in, while the policy segment's is still in flight); `bump=False` on every call but the first of an
+        optimiser step, so that the step count advances once."""
+        if bump:
+            state["count"] += 1
+        if segment is not None:
+            sub = {"mu": state["mu"][segment], "nu": state["nu"][segment], "count": state["count"]}
+            return self.update(grads[segment], sub, params[segment], bump=False)
         lib = self.lib
         if lib is None and params.is_cuda:
             from .. import _lib
@@ -231,7 +240,7 @@ def train(
             use_hip_update = False
     _METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "entropy_loss", "kl_loss_intention", "explained_variance")
 
-    def hip_grad(data_tm: acting.Transition, normalizer_params, noise) -> Metrics:
+    def hip_grad(data_tm: acting.Transition, normalizer_params, noise, part: int = 0) -> Metrics:
         """d loss / d flat -> flat_grad by the hand-written kernels; `data_tm` time-major [T, mb, ...]."""
         T, mb = data_tm.reward.shape[:2]
         if (T, mb) not in hip_upd:
@@ -240,11 +249,48 @@ def train(
                 gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage,
                 kl_weight=kl_weight)
         upd = hip_upd[(T, mb)]
-        mt = upd.grad(training_state.params, normalizer_params, data_tm, noise, flat_grad)
+        mt = upd.grad(training_state.params, normalizer_params, data_tm, noise, flat_grad, part=part)
         hip_upd["last_metrics"] = mt
         metrics = {k: mt[i] for i, k in enumerate(_METRIC_KEYS)}
         metrics["prediction_corr"] = mt[8]  # computed by the library beside the backward passes
         return metrics
+
+    # C1, in the order the segments of the flat buffer become final: the value network's gradients (its chain joins first,
+    # csrc/vnl_ppo.hip part 1), then the policy's.  Each segment is all-reduced on a communication stream of its own as soon
+    # as it is final and Adam updates it as soon as its exchange is in: the value exchange (79 % of the bytes) overlaps the
+    # policy network's backward, the policy exchange overlaps the value segment's Adam.  (reference train.py:251-268: one
+    # pmean of the whole gradient per minibatch step, after the backward pass.)
+    segments = (("value", slice(n_pol, n_pol + n_val)), ("policy", slice(0, n_pol)))
+    comm_stream = torch.cuda.Stream(device) if (dist is not None and device.type == "cuda") else None
+
+    def exchange(seg: slice):
+        """all-reduce(mean) of one segment of flat_grad, enqueued behind what the current stream holds; returns a handle"""
+        view = flat_grad[seg]
+        if comm_stream is None:
+            return dist.all_reduce(view, async_op=True)
+        comm_stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(comm_stream):
+            work = dist.all_reduce(view, async_op=True)
+        return work
+
+    def finish(work, seg: slice, first: bool) -> None:
+        """wait for a segment's exchange, average it, apply Adam to it"""
+        work.wait()  # (on a HIP device: makes the current stream wait for the collective, no host block)
+        if comm_stream is not None:
+            torch.cuda.current_stream(device).wait_stream(comm_stream)
+        flat_grad[seg].div_(world)
+        optimizer.update(flat_grad, training_state.optimizer_state, training_state.params, segment=seg, bump=first)
+
+    def sync_and_step(between=None) -> None:
+        """C1 + Adam for one minibatch step.  `between`: work to enqueue after the value segment's exchange has been issued
+        (the policy network's backward when the step is split: hip_update part 2)."""
+        (_, vseg), (_, pseg) = segments
+        wv = exchange(vseg)
+        if between is not None:
+            between()
+        wp = exchange(pseg)
+        finish(wv, vseg, True)
+        finish(wp, pseg, False)
 
     def minibatch_step(data: acting.Transition, normalizer_params) -> Metrics:
         """train.py:255-268 + brax gradient_update_fn: grad, all-reduce(mean), adam."""
@@ -254,10 +300,11 @@ def train(
             noise = {"latent": torch.randn((T, mb, ppo_network.policy_module.latents), generator=g_dev, device=device),
                      "entropy": torch.randn((T, mb, ppo_network.parametric_action_distribution.event_size), generator=g_dev,
                                             device=device)}
+            if dist is not None:  # split step: the value segment's exchange overlaps the policy network's backward
+                metrics = hip_grad(tm, normalizer_params, noise, part=1)
+                sync_and_step(between=lambda: hip_grad(tm, normalizer_params, noise, part=2))
+                return metrics
             metrics = hip_grad(tm, normalizer_params, noise)
-            if dist is not None:
-                dist.all_reduce(flat_grad)  # C1: one flat buffer
-                flat_grad.div_(world)
             optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
             return metrics
         leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
@@ -265,9 +312,9 @@ def train(
         loss.backward()
         leaf_params.policy.gather_grads(), leaf_params.value.gather_grads()
         if dist is not None:
-            dist.all_reduce(flat_grad)  # C1: one flat buffer
-            flat_grad.div_(world)
-        optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
+            sync_and_step()  # C1 (autograd delivers both segments at once: nothing to overlap with, same call structure)
+        else:
+            optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
         return metrics
 
     if capture_graph is None:
@@ -309,11 +356,17 @@ def train(
             o.width = int(sr[0, 0].numel())
         g["gather_desc"], lib = gd, base._L
 
+        split = dist is not None and use_hip_update  # two graphs: [gather, forward, head, value backward] | [policy backward]
+        g["split"] = split
+
+        def body2():
+            hip_grad(g["mb"], g["norm"], g["noise"], part=2)
+
         def body():
             _lib.check(lib, lib.vnl_gather_rows(C.byref(gd), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
             mbd = g["mb"]
             if use_hip_update:
-                metrics = hip_grad(mbd, g["norm"], g["noise"])
+                metrics = hip_grad(mbd, g["norm"], g["noise"], part=1 if split else 0)
             else:
                 leaf_params.policy.zero_grad(), leaf_params.value.zero_grad()
                 loss, metrics = loss_fn(leaf_params, g["norm"], mbd, None, noise=g["noise"], time_major=True)
@@ -328,6 +381,8 @@ def train(
         with torch.cuda.stream(side):
             for _ in range(3):  # warm-up off the capture stream (library handles, autograd buffers)
                 m = body()
+                if split:
+                    body2()
         torch.cuda.current_stream(device).wait_stream(side)
         g["keys"] = sorted(m.keys())
         g["acc"] = torch.zeros(len(g["keys"]), device=device)
@@ -342,6 +397,10 @@ def train(
                 g["acc"] += hip_upd["last_metrics"][g["slots"]]
             else:
                 g["acc"] += torch.stack([m[k].to(torch.float32).reshape(()) for k in g["keys"]])
+        if split:
+            g["graph2"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["graph2"]):
+                body2()
         with torch.no_grad():  # the warm-up iterations must not count as training
             p.copy_(saved[0])
             for k, v in saved[1].items():
@@ -358,10 +417,8 @@ def train(
             for name in ("latent", "entropy"):  # same draws, same order as the eager loss
                 torch.randn(g["noise"][name].shape, generator=g_dev, device=device, out=g["noise"][name])
             g["graph"].replay()
-            if dist is not None:
-                dist.all_reduce(flat_grad)  # C1
-                flat_grad.div_(world)
-                optimizer.update(flat_grad, training_state.optimizer_state, training_state.params)
+            if dist is not None:  # C1 + Adam, eager between the replays (segments: see sync_and_step)
+                sync_and_step(between=g["graph2"].replay if g["split"] else None)
         acc = g["acc"] / num_minibatches
         return {k: acc[i] for i, k in enumerate(g["keys"])}
 
