@@ -58,6 +58,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define VNL_SERIAL if (true)
 #define VNL_SYNC()
+#define VNL_SYNC_GLOBAL()
 #define VNL_LDS_DECL(name) static thread_local vreal name[32768]
 #define vnl_wave_sum(x) (x)
 #define vnl_wave_any(x) (x)

@@ -48,7 +48,20 @@
 #define VNL_ROWSETS_2 2 /* .. or nv <= 128 */
 #define VNL_FOR(i, n) for (int i = (int)lane; i < (n); i += VNL_LANES)
 #define VNL_SERIAL if (lane == 0)
-#define VNL_SYNC() __syncthreads()
+// Join of a fork-join region.  The workgroup IS one wave: its LDS operations execute in issue order, so data one lane wrote
+// to LDS is what any lane's later ds_read returns -- the region boundary needs no wait at all (what __syncthreads() compiles
+// to here is no s_barrier but a full `s_waitcnt vmcnt(0) lgkmcnt(0)`: an exposed LDS round trip at each of the several
+// hundred joins of a substep), only that the compiler keeps the accesses in order: the wavefront-scope fence, no instruction.
+#define VNL_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+// .. and the join behind GLOBAL memory that one lane wrote and another lane will read (xpos / xquat in the state buffers:
+// kinematics -> make_constraint and the env glue; the second factor's scratch: invert_pair -> euler): the vector-memory
+// counter is drained, so the stores have reached the cache the loads are served from
+#define VNL_SYNC_GLOBAL()                                     \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+  } while (0)
 #define VNL_LDS_DECL(name) extern __shared__ __align__(16) vreal name[]
 // Cross-lane sum with DPP (VALU-rate) instead of ds_bpermute: xor-butterfly inside each row of 16 lanes (quad_perm,
 // row_half_mirror, row_mirror: every lane then holds its row's total), the row totals combined by row_bcast:15 (rows 1, 3
@@ -456,7 +469,7 @@ struct EnvWave {
         st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
       }
     }
-    VNL_SYNC();
+    VNL_SYNC_GLOBAL();  // (xpos / xquat went to the state buffers: read across lanes from here on)
   }
 
   // com_pos: cinert about O in world axes, R I R' + m(|r|^2 1 - r r'), r = xipos - O -> pool[0..10 nbody); optionally com
@@ -2372,6 +2385,7 @@ struct EnvWave {
       // into the pool (the constraint rows are dead now) and apply it
       const vreal* g2 = fac2();
       const int n2 = m.nM + m.nv;
+      VNL_SYNC_GLOBAL();  // (written by invert_pair, one row per lane; read here element by element)
       VNL_FOR(k, n2) s[L.P + k] = g2[k];
       VNL_SYNC();
       fresh().solve_inplace(L.tmp, L.P, L.P + m.nM);
@@ -2575,6 +2589,7 @@ struct EnvWave {
     VNL_FOR(d, m.nv) s[L.qacc + d] = vreal(0.);
     VNL_SYNC();
     with_trace(trace_of(trace_base, 0)).forward(s + L.qacc);  // qacc_warmstart = 0 (mjx.make_data)
+    VNL_SYNC_GLOBAL();
     store_state();
     write_traj(clip, sf);
     write_obs();
@@ -2665,7 +2680,7 @@ struct EnvWave {
         vreal* mt = st.metrics + (size_t)e * 7;
         mt[0] = r0.rcom, mt[1] = r0.rvel, mt[2] = r0.rquat, mt[3] = r0.ract, mt[4] = r0.rapp, mt[5] = r0.healthy;
       }
-      VNL_SYNC();
+      VNL_SYNC_GLOBAL();
     }
     VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
@@ -2674,13 +2689,14 @@ struct EnvWave {
       fresh().euler();
     }
     int new_frame = old_frame + 1, new_sub = old_sub + 1;
+    VNL_SYNC_GLOBAL();  // (the glue reads xpos / xquat / qfrc_actuator of the last forward pass across lanes)
     RewardTerms rw;
     if (!(ev.flags & VNL_ENV_REWARD_OLD_STATE)) {  // rodent.py:195: _calculate_reward(state, data) -- the NEW data
       rw = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, s + L.com, gqfrc_act(), gxpos(), ac);
     } else {
       const vreal* mt = st.metrics + (size_t)e * 7;
       rw = RewardTerms{mt[0], mt[1], mt[2], mt[3], mt[4], mt[5]};
-      VNL_SYNC();  // (every lane has read the parked values before lane 0 rewrites the row below)
+      VNL_SYNC_GLOBAL();  // (every lane has read the parked values before lane 0 rewrites the row below)
     }
     const vreal done_trunk = rtrunk < ev.done_threshold ? vreal(1.) : vreal(0.);  // on the unscaled value (rodent.py:213: < 0)
     // weighted terms, then their sum in the reference's order (rodent.py:203-210; ant.py:182-188)
