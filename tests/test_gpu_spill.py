@@ -82,3 +82,32 @@ def test_packed_factorisation_equals_the_plain_form_bit_for_bit():
     worst = {k: float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()) for k in outs[0]}
     print("\n[packed vs plain factor_pair, 3 steps, 512 envs] bitwise equal:", same, "largest difference:", worst)
     assert all(same.values()), (same, worst)
+
+
+def test_specialised_kernels_equal_the_generic_kernels_bit_for_bit():
+    """The rodent runs kernels SPECIALISED at compile time for its dimensions and LDS layout (csrc/vnl_types.h VnlSpecRodent:
+    loop bounds fold, offsets become instruction immediates); csrc/build.py --nospec builds the same sources with the
+    specialisation switched off, so that the generic kernels (every dimension read from the constant block: what any other
+    model runs) take the rodent too.  Same operations on the same operands in the same order: bit-identical outputs."""
+    from vnl_brax_imitation_amd import _lib
+    from vnl_brax_imitation_amd.csrc import build as hip_build
+
+    path = hip_build.build(variant="nospec")
+    B = 512
+    rng = np.random.default_rng(44)
+    sf = rng.integers(0, 235, B).astype(np.int32)
+    noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
+    acts = np.clip(0.3 * rng.standard_normal((3, B, 30)), -1, 1).astype(np.float32)
+    outs = []
+    for env in (_env(B, _lib.load_library(path)), _env(B)):
+        s = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+        for a in acts:
+            s = env.step(s, torch.from_numpy(a))
+        ps = s.pipeline_state
+        outs.append({k: getattr(ps, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc_warmstart", "xpos")} |
+                    {"obs": s.obs.cpu().numpy().copy(), "reward": s.reward.cpu().numpy().copy(),
+                     "traj": s.info["traj"].cpu().numpy().copy()})
+    same = {k: bool(np.array_equal(outs[0][k], outs[1][k])) for k in outs[0]}
+    worst = {k: float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()) for k in outs[0]}
+    print("\n[specialised vs generic kernels, 3 steps, 512 envs] bitwise equal:", same, "largest difference:", worst)
+    assert all(same.values()), (same, worst)

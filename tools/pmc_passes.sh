@@ -12,7 +12,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc_$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --random-actions --steps 6 --warmup 2 --no-cpu-baseline > $OUT/run_$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc_$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --random-actions --steps 6 --warmup 2 --no-cpu-baseline --no-train-step > $OUT/run_$i.log 2>&1
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_$i vnl_step > $OUT/pass_$i.txt
   cat $OUT/pass_$i.txt
 done

@@ -17,14 +17,18 @@ OUT = os.path.join(HERE, "libvnl.so")
 #   spill  env kernels compiled under a 128-VGPR cap, which forces ~230 registers per lane to spill to scratch
 #          memory: results must not depend on spilling (tests/test_gpu_spill.py)
 VARIANTS = {
-    "product": ("libvnl.so", []),
+    # (the product holds its env kernels to two waves per SIMD: the specialised instantiations, every bound a constant, are
+    # unrolled further by the compiler and would otherwise take a 257th register -- half the occupancy)
+    "product": ("libvnl.so", ["-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     # (the diagnostic variants carry extra code: held to the product's two waves per SIMD so that their timings stay comparable)
     "prof": ("libvnl_prof.so", ["-DVNL_PROFILE", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     "knobs": ("libvnl_knobs.so", ["-DVNL_STAGE_KNOBS", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     "spill": ("libvnl_spill.so", ["-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(4,4)))"]),
     # the two factorisations of a substep in the plain form (one lane set per 64 rows, one v_fma_f32 per system): the form the
     # host simulation compiles; the product's packed form must agree with it bit for bit (tests/test_gpu_spill.py)
-    "unpacked": ("libvnl_unpacked.so", ["-DVNL_FAC_UNPACKED"]),
+    "unpacked": ("libvnl_unpacked.so", ["-DVNL_FAC_UNPACKED", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
+    # the generic kernels (dims and LDS offsets read at run time) on the rodent too: the specialised ones must agree bit for bit
+    "nospec": ("libvnl_nospec.so", ["-DVNL_NO_SPEC", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
 }
 ENV_KERNELS = ("vnl_step_kernel", "vnl_reset_kernel")
 
@@ -77,8 +81,7 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, kno
         os.remove(out)
         raise RuntimeError(f"no resource-usage remark for {missing}: cannot check the register budget of this build")
     if variant == "product":
-        for k, v in seen.items():
-            u = v[0]
+        for k, u in ((k, u) for k, v in seen.items() for u in v):
             if u.get("ScratchSize [bytes/lane]", 0) != 0 or u["Occupancy [waves/SIMD]"] < 2:
                 if os.environ.get("VNL_ALLOW_SPILL") != "1":
                     os.remove(out)

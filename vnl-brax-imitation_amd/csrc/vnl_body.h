@@ -142,8 +142,8 @@ __device__ unsigned long long g_vnl_prof[VNL_NPROF];
   do {                                                                                          \
     if (lane == 0) {                                                                            \
       unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                     \
-      s[L.prof + (i)] += (float)(t_ - __builtin_bit_cast(unsigned, (float)s[L.prof + VNL_NPROF])); \
-      s[L.prof + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime()); \
+      s[LO(prof) + (i)] += (float)(t_ - __builtin_bit_cast(unsigned, (float)s[LO(prof) + VNL_NPROF])); \
+      s[LO(prof) + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime()); \
     }                                                                                           \
   } while (0)
 #else
@@ -212,7 +212,12 @@ VNL_HD S6 mcross_force(S6 v, S6 f) { return S6{cross(v.a, f.a) + cross(v.l, f.l)
 #define VNL_TO_CAS(T, p) ((const T*)(p))
 #define VNL_LAUNDER(p)
 #endif
-struct EnvWave {
+// SP: the compile-time model of this instantiation (csrc/vnl_types.h: VnlSpecGeneric reads every dimension and LDS offset
+// from the constant block, VnlSpecRodent has them as constants)
+#define MI(f) (SP::fixed ? SP::D.f : m.f)
+#define LO(f) (SP::fixed ? SP::L.f : L.f)
+template <class SP>
+struct EnvWaveT {
   const VNL_CAS DevModel& m;
   const VNL_CAS DevEnv& ev;
   const DevState& st;
@@ -224,22 +229,22 @@ struct EnvWave {
   // The same view with the constant block's address made opaque to the optimiser: constants read by the stage that
   // follows are loaded there (scalar loads) instead of being kept alive -- spilled to VGPR lanes and fetched back
   // with v_readlane -- from the top of the kernel.
-  VNL_HD EnvWave with_trace(int* t) const { return EnvWave{m, ev, st, L, s, e, lane, kc, t}; }
-  VNL_HD EnvWave fresh() const {
+  VNL_HD EnvWaveT with_trace(int* t) const { return EnvWaveT{m, ev, st, L, s, e, lane, kc, t}; }
+  VNL_HD EnvWaveT fresh() const {
     const VNL_CAS KernelConsts* k = kc;
     VNL_LAUNDER(k);
-    return EnvWave{k->m, k->ev, st, k->L, s, e, lane, k, trace};
+    return EnvWaveT{k->m, k->ev, st, k->L, s, e, lane, k, trace};
   }
 #ifdef VNL_PROFILE
   VNL_HD void prof_begin() const {
     if (lane == 0) {
-      for (int i = 0; i < VNL_NPROF; i++) s[L.prof + i] = 0.f;
-      s[L.prof + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
+      for (int i = 0; i < VNL_NPROF; i++) s[LO(prof) + i] = 0.f;
+      s[LO(prof) + VNL_NPROF] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
     }
   }
   VNL_HD void prof_end() const {
     if (lane == 0)
-      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], (unsigned long long)s[L.prof + i]);
+      for (int i = 0; i < VNL_NPROF; i++) atomicAdd(&g_vnl_prof[i], (unsigned long long)s[LO(prof) + i]);
   }
 #else
   VNL_HD void prof_begin() const {}
@@ -267,11 +272,11 @@ struct EnvWave {
   }
 
   // xpos / xquat / qfrc_actuator live in their (caller-owned, L2-resident) state buffers, not in LDS
-  VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * m.nbody; }
-  VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * m.nbody; }
-  VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * m.nv; }
+  VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * MI(nbody); }
+  VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * MI(nbody); }
+  VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * MI(nv); }
   // library-owned global scratch of this env: the second factor of a substep (factor_pair), nM + nv elements
-  VNL_HD vreal* fac2() const { return ev.fac2 + (size_t)e * (m.nM + m.nv); }
+  VNL_HD vreal* fac2() const { return ev.fac2 + (size_t)e * (MI(nM) + MI(nv)); }
   VNL_HD V3 gpos3(int b) const {
     const vreal* x = gxpos() + 3 * b;
     return V3{x[0], x[1], x[2]};
@@ -280,23 +285,23 @@ struct EnvWave {
     const vreal* q = gxquat() + 4 * b;
     return Q4{q[0], q[1], q[2], q[3]};
   }
-  VNL_HD V3 ref_point() const { return m.root_free ? ld3(L.qpos) : V3{m.root_px, m.root_py, m.root_pz}; }
+  VNL_HD V3 ref_point() const { return MI(root_free) ? ld3(LO(qpos)) : V3{m.root_px, m.root_py, m.root_pz}; }
 
   // ---- small index tables staged in LDS (dependent lookups in the sparse linear algebra and in the
   // tree walks would otherwise each pay a global / scalar-cache round trip)
-  VNL_HD int anc_of(int k) const { return ((const unsigned char*)(s + L.tab_anc))[k]; }  // column dof of entry k
-  VNL_HD int madr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[d]; }            // first entry of row d
-  VNL_HD int eadr(int d) const { return ((const unsigned short*)(s + L.tab_madr))[m.nv + d]; }     // madr(d) + depth(d)
+  VNL_HD int anc_of(int k) const { return ((const unsigned char*)(s + LO(tab_anc)))[k]; }  // column dof of entry k
+  VNL_HD int madr(int d) const { return ((const unsigned short*)(s + LO(tab_madr)))[d]; }            // first entry of row d
+  VNL_HD int eadr(int d) const { return ((const unsigned short*)(s + LO(tab_madr)))[MI(nv) + d]; }     // madr(d) + depth(d)
   VNL_HD int depth(int d) const { return eadr(d) - madr(d); }
-  VNL_HD int ndesc(int d) const { return ((const unsigned short*)(s + L.tab_madr))[2 * m.nv + d]; }       // descendants of dof d
-  VNL_HD int parent_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[b]; }
-  VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[m.nbody + b]; }
-  VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + L.tab_body))[2 * m.nbody + b]; }
-  VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + c]; }
+  VNL_HD int ndesc(int d) const { return ((const unsigned short*)(s + LO(tab_madr)))[2 * MI(nv) + d]; }       // descendants of dof d
+  VNL_HD int parent_of(int b) const { return ((const unsigned char*)(s + LO(tab_body)))[b]; }
+  VNL_HD int dofadr_of(int b) const { return ((const unsigned char*)(s + LO(tab_body)))[MI(nbody) + b]; }
+  VNL_HD int dofnum_of(int b) const { return ((const unsigned char*)(s + LO(tab_body)))[2 * MI(nbody) + b]; }
+  VNL_HD int con_body(int c) const { return ((const unsigned char*)(s + LO(tab_body)))[3 * MI(nbody) + c]; }
   // last dof on the path of contact c's body (== nv if the body hangs off the world without dofs)
   // compact list of the constraint rows that exist (after the active-contact list and the two counters)
-  VNL_HD unsigned short* live_rows() const { return (unsigned short*)((int*)(s + L.act_list) + (m.ncon + 3) / 4 + 2); }
-  VNL_HD int num_live_rows() const { return ((const int*)(s + L.act_list))[(m.ncon + 3) / 4 + 1]; }
+  VNL_HD unsigned short* live_rows() const { return (unsigned short*)((int*)(s + LO(act_list)) + (MI(ncon) + 3) / 4 + 2); }
+  VNL_HD int num_live_rows() const { return ((const int*)(s + LO(act_list)))[(MI(ncon) + 3) / 4 + 1]; }
   // body(r) for every constraint row that exists -- through the compact list when it holds them all (the rows make_constraint
   // masked out have D = 0 and never contribute to a cost, force or gradient, so their Jaref / jv need no upkeep)
   template <class F>
@@ -306,37 +311,37 @@ struct EnvWave {
       const unsigned short* lv = live_rows();
       VNL_FOR(l, nl) body((int)lv[l]);
     } else {
-      VNL_FOR(r, m.nefc) body(r);
+      VNL_FOR(r, MI(nefc)) body(r);
     }
   }
-  VNL_HD int con_lastdof(int c) const { return ((const unsigned char*)(s + L.tab_body))[3 * m.nbody + m.ncon + c]; }
+  VNL_HD int con_lastdof(int c) const { return ((const unsigned char*)(s + LO(tab_body)))[3 * MI(nbody) + MI(ncon) + c]; }
   // dofs sorted by depth: lvl_dof(q) for q in [lvl_start(l), lvl_start(l+1)) are the dofs of depth l
-  VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + L.tab_lvl))[q]; }
-  VNL_HD int lvl_start(int l) const { return ((const unsigned char*)(s + L.tab_lvl))[m.nv + l]; }
-  VNL_HD int jump_of(int r, int b) const { return ((const unsigned char*)(s + L.tab_jump))[r * m.nbody + b]; }
+  VNL_HD int lvl_dof(int q) const { return ((const unsigned char*)(s + LO(tab_lvl)))[q]; }
+  VNL_HD int lvl_start(int l) const { return ((const unsigned char*)(s + LO(tab_lvl)))[MI(nv) + l]; }
+  VNL_HD int jump_of(int r, int b) const { return ((const unsigned char*)(s + LO(tab_jump)))[r * MI(nbody) + b]; }
   VNL_HD void load_tables() const {
-    unsigned char* ta = (unsigned char*)(s + L.tab_anc);
-    VNL_FOR(k, m.nM) ta[k] = (unsigned char)m.M_anc[k];
-    unsigned short* tm = (unsigned short*)(s + L.tab_madr);
-    VNL_FOR(d, m.nv) {
-      tm[d] = (unsigned short)m.dof_Madr[d], tm[m.nv + d] = (unsigned short)(m.dof_Madr[d] + m.dof_depth[d]);
-      tm[2 * m.nv + d] = (unsigned short)m.dof_ndesc[d];
+    unsigned char* ta = (unsigned char*)(s + LO(tab_anc));
+    VNL_FOR(k, MI(nM)) ta[k] = (unsigned char)m.M_anc[k];
+    unsigned short* tm = (unsigned short*)(s + LO(tab_madr));
+    VNL_FOR(d, MI(nv)) {
+      tm[d] = (unsigned short)m.dof_Madr[d], tm[MI(nv) + d] = (unsigned short)(m.dof_Madr[d] + m.dof_depth[d]);
+      tm[2 * MI(nv) + d] = (unsigned short)m.dof_ndesc[d];
     }
-    unsigned char* tb = (unsigned char*)(s + L.tab_body);
-    VNL_FOR(b, m.nbody) {
+    unsigned char* tb = (unsigned char*)(s + LO(tab_body));
+    VNL_FOR(b, MI(nbody)) {
       tb[b] = (unsigned char)m.body_parent[b];
-      tb[m.nbody + b] = (unsigned char)m.body_dofadr[b];
-      tb[2 * m.nbody + b] = (unsigned char)m.body_dofnum[b];
+      tb[MI(nbody) + b] = (unsigned char)m.body_dofadr[b];
+      tb[2 * MI(nbody) + b] = (unsigned char)m.body_dofnum[b];
     }
-    VNL_FOR(c, m.ncon) {
+    VNL_FOR(c, MI(ncon)) {
       int cb = m.cg_body[m.con_geom[c] & 0xff];
-      tb[3 * m.nbody + c] = (unsigned char)cb;
-      tb[3 * m.nbody + m.ncon + c] = (unsigned char)m.body_lastdof[cb];
+      tb[3 * MI(nbody) + c] = (unsigned char)cb;
+      tb[3 * MI(nbody) + MI(ncon) + c] = (unsigned char)m.body_lastdof[cb];
     }
-    unsigned char* tl = (unsigned char*)(s + L.tab_lvl);
-    VNL_FOR(q, m.nv + m.max_depth + 2) tl[q] = m.lvl_tab[q];
-    unsigned char* tj = (unsigned char*)(s + L.tab_jump);
-    VNL_FOR(q, m.jump_rounds * m.nbody) tj[q] = m.jump[q];
+    unsigned char* tl = (unsigned char*)(s + LO(tab_lvl));
+    VNL_FOR(q, MI(nv) + MI(max_depth) + 2) tl[q] = m.lvl_tab[q];
+    unsigned char* tj = (unsigned char*)(s + LO(tab_jump));
+    VNL_FOR(q, MI(jump_rounds) * MI(nbody)) tj[q] = m.jump[q];
     VNL_SYNC();
   }
 
@@ -346,8 +351,8 @@ struct EnvWave {
   // ancestor (0 = none), log2(depth) rounds, ping-pong between buf0 and buf1.
   VNL_HD int tree_prefix(int buf0, int buf1) const {
     int src = buf0, dst = buf1;
-    for (int r = 0; r < m.jump_rounds; r++) {
-      VNL_FOR(i, 6 * m.nbody) {
+    for (int r = 0; r < MI(jump_rounds); r++) {
+      VNL_FOR(i, 6 * MI(nbody)) {
         int b = i / 6, j = jump_of(r, b);
         vreal v = s[src + i];
         if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
@@ -363,9 +368,9 @@ struct EnvWave {
   // In-place variant (one buffer): every element first reads its own and its jump-ancestor's value
   // into registers, then -- after a barrier -- writes the sum back.
   VNL_HD void tree_prefix_inplace(int buf) const {
-    for (int r = 0; r < m.jump_rounds; r++) {
+    for (int r = 0; r < MI(jump_rounds); r++) {
       vreal keep[VNL_PREFIX_PER_LANE];
-      int n = 6 * m.nbody, q = 0;
+      int n = 6 * MI(nbody), q = 0;
       VNL_FOR(i, n) {
         int b = i / 6, j = jump_of(r, b);
         vreal v = s[buf + i];
@@ -387,8 +392,8 @@ struct EnvWave {
   //      jumping (log2(depth) rounds) -- composition of rigid transforms is associative;
   //  (3) per dof, in parallel: cdof from the parent's world pose and the local anchor / axis.
   VNL_HD void kinematics() const {
-    int A = L.P, Bf = L.P + 7 * m.nbody;  // 7 floats per body: pos(3) quat(4)
-    VNL_FOR(b, m.nbody) {
+    int A = LO(P), Bf = LO(P) + 7 * MI(nbody);  // 7 floats per body: pos(3) quat(4)
+    VNL_FOR(b, MI(nbody)) {
       V3 pos = v3(vreal(0.), vreal(0.), vreal(0.));
       Q4 quat = Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)};
       if (b > 0) {
@@ -397,18 +402,18 @@ struct EnvWave {
         for (int k = 0; k < jn; k++) {
           int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
           if (m.jnt_type[j] == VNL_JNT_FREE) {
-            pos = ld3(L.qpos + qa);
-            quat = ld4(L.qpos + qa + 3);
+            pos = ld3(LO(qpos) + qa);
+            quat = ld4(LO(qpos) + qa + 3);
             vreal n = sqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
             vreal inv = n > vreal(0.) ? vreal(1.) / n : vreal(1.);
             quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
-            s[L.qpos + qa + 3] = quat.w, s[L.qpos + qa + 4] = quat.x, s[L.qpos + qa + 5] = quat.y,
-                            s[L.qpos + qa + 6] = quat.z;  // normalised quaternion written back
+            s[LO(qpos) + qa + 3] = quat.w, s[LO(qpos) + qa + 4] = quat.x, s[LO(qpos) + qa + 5] = quat.y,
+                            s[LO(qpos) + qa + 6] = quat.z;  // normalised quaternion written back
           } else {
             V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
             V3 anchor = qrot(jp, quat) + pos;
-            st6(L.cdof + 6 * da, S6{qrot(jax, quat), anchor});  // (axis, anchor) in the parent frame, for phase 3
-            vreal ang = s[L.qpos + qa] - m.jnt_qpos0[j];
+            st6(LO(cdof) + 6 * da, S6{qrot(jax, quat), anchor});  // (axis, anchor) in the parent frame, for phase 3
+            vreal ang = s[LO(qpos) + qa] - m.jnt_qpos0[j];
             vreal sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
             quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
             pos = anchor - qrot(jp, quat);
@@ -420,8 +425,8 @@ struct EnvWave {
     }
     VNL_SYNC();
     int src = A, dst = Bf;
-    for (int r = 0; r < m.jump_rounds; r++) {
-      VNL_FOR(b, m.nbody) {
+    for (int r = 0; r < MI(jump_rounds); r++) {
+      VNL_FOR(b, MI(nbody)) {
         int j = jump_of(r, b);
         V3 pos = ld3(src + 7 * b);
         Q4 quat = ld4(src + 7 * b + 3);
@@ -439,34 +444,34 @@ struct EnvWave {
     }
     vreal* gx = gxpos();
     vreal* gq = gxquat();
-    VNL_FOR(b, m.nbody) {
+    VNL_FOR(b, MI(nbody)) {
       V3 p = ld3(src + 7 * b);
       Q4 q = ld4(src + 7 * b + 3);
       gx[3 * b] = p.x, gx[3 * b + 1] = p.y, gx[3 * b + 2] = p.z;
       gq[4 * b] = q.w, gq[4 * b + 1] = q.x, gq[4 * b + 2] = q.y, gq[4 * b + 3] = q.z;
     }
     V3 O = ref_point();
-    VNL_FOR(j, m.njnt) {
+    VNL_FOR(j, MI(njnt)) {
       int bd = m.jnt_body[j], da = m.jnt_dofadr[j];
       if (m.jnt_type[j] == VNL_JNT_FREE) {
         M3 R = qmat(ld4(src + 7 * bd + 3));
         V3 off = O - ld3(src + 7 * bd);
         for (int t = 0; t < 3; t++) {
-          int o = L.cdof + 6 * (da + t);
+          int o = LO(cdof) + 6 * (da + t);
           s[o] = vreal(0.), s[o + 1] = vreal(0.), s[o + 2] = vreal(0.);
           s[o + 3] = t == 0 ? vreal(1.) : vreal(0.), s[o + 4] = t == 1 ? vreal(1.) : vreal(0.),
                 s[o + 5] = t == 2 ? vreal(1.) : vreal(0.);
         }
         for (int t = 0; t < 3; t++) {
           V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
-          st6(L.cdof + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
+          st6(LO(cdof) + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
         }
       } else {
         int p = parent_of(bd);
         Q4 pq = ld4(src + 7 * p + 3);
-        S6 la = ld6(L.cdof + 6 * da);
+        S6 la = ld6(LO(cdof) + 6 * da);
         V3 axis = qrot(la.a, pq), anchor = ld3(src + 7 * p) + qrot(la.l, pq);
-        st6(L.cdof + 6 * da, S6{axis, cross(axis, O - anchor)});
+        st6(LO(cdof) + 6 * da, S6{axis, cross(axis, O - anchor)});
       }
     }
     VNL_SYNC_GLOBAL();  // (xpos / xquat went to the state buffers: read across lanes from here on)
@@ -476,8 +481,8 @@ struct EnvWave {
   VNL_HD void body_inertias(bool with_com) const {
     V3 O = ref_point();
     V3 csum = v3(vreal(0.), vreal(0.), vreal(0.));
-    VNL_FOR(b, m.nbody) {
-      int o = L.P + 10 * b;
+    VNL_FOR(b, MI(nbody)) {
+      int o = LO(P) + 10 * b;
       if (b == 0) {
         for (int k = 0; k < 10; k++) s[o + k] = vreal(0.);
         continue;
@@ -504,7 +509,7 @@ struct EnvWave {
     }
     if (with_com) {
       vreal cx = vnl_wave_sum(csum.x), cy = vnl_wave_sum(csum.y), cz = vnl_wave_sum(csum.z);
-      VNL_SERIAL { st3(L.com, v3(cx * m.total_mass_inv, cy * m.total_mass_inv, cz * m.total_mass_inv)); }
+      VNL_SERIAL { st3(LO(com), v3(cx * m.total_mass_inv, cy * m.total_mass_inv, cz * m.total_mass_inv)); }
     }
     VNL_SYNC();
   }
@@ -516,7 +521,7 @@ struct EnvWave {
   VNL_HD void tree_accumulate(int base, int width) const {
     VNL_FOR(k, width) {
       vreal carry = vreal(0.);
-      int b = m.nbody - 1;
+      int b = MI(nbody) - 1;
       constexpr int G = 8;  // bodies per trip
       for (; b >= 1 && (b & (G - 1)) != G - 1; b--) {  // down to a group boundary
         const int o = base + width * b + k;
@@ -537,7 +542,7 @@ struct EnvWave {
         const int o = base + width * b0 + k;
         unsigned pw[G / 4];
 #pragma unroll
-        for (int j = 0; j < G / 4; j++) pw[j] = (unsigned)VNL_UNIFORM_I((int)((const unsigned*)(s + L.tab_body))[(b0 >> 2) + j]);
+        for (int j = 0; j < G / 4; j++) pw[j] = (unsigned)VNL_UNIFORM_I((int)((const unsigned*)(s + LO(tab_body)))[(b0 >> 2) + j]);
         vreal x[G], x0[G];
 #pragma unroll
         for (int j = 0; j < G; j++) x0[j] = x[j] = s[o + width * j];
@@ -572,18 +577,18 @@ struct EnvWave {
   // smooth.crb + make_m straight into the factor buffer: LD <- qM + diag_scale * diag(damping).
   // Expects cinert in pool[0..10 nbody) (turned into crb in place).
   VNL_HD void mass_matrix(vreal diag_scale) const {
-    tree_accumulate(L.P, 10);
+    tree_accumulate(LO(P), 10);
     VNL_PROF(5);
     // f_i = crb[body(i)] * cdof_i for every dof, parked in the six CG vectors Ma .. qfrc_c (contiguous,
     // dead whenever M is built); then one lane per run of consecutive matrix ENTRIES (not per row: rows
     // have 1 .. max_depth+1 entries): M(i, j) = f_i . cdof_j.
-    const int F = L.Ma;
-    VNL_FOR(i, m.nv) st6(F + 6 * i, inert_mul(L.P + 10 * m.dof_body[i], ld6(L.cdof + 6 * i)));
+    const int F = LO(Ma);
+    VNL_FOR(i, MI(nv)) st6(F + 6 * i, inert_mul(LO(P) + 10 * m.dof_body[i], ld6(LO(cdof) + 6 * i)));
     VNL_SYNC();
-    const int per = (m.nM + VNL_LANES - 1) / VNL_LANES;
+    const int per = (MI(nM) + VNL_LANES - 1) / VNL_LANES;
     VNL_FOR(l, VNL_LANES) {
       int e = l * per;
-      const int e1 = e + per < m.nM ? e + per : m.nM;
+      const int e1 = e + per < MI(nM) ? e + per : MI(nM);
       if (e < e1) {
         int i = m.M_row[e], end = eadr(i);
         S6 f = ld6(F + 6 * i);
@@ -594,23 +599,23 @@ struct EnvWave {
             f = ld6(F + 6 * i);
           }
           const int j = anc_of(e);
-          s[L.LD + e] = dot(f, ld6(L.cdof + 6 * j));
+          s[LO(LD) + e] = dot(f, ld6(LO(cdof) + 6 * j));
         }
       }
     }
     VNL_SYNC();
     // armature and (Euler step) h * damping on the diagonals, one lane per dof: inside the entry loop these two table
     // reads were an L2 round trip in the middle of a serial chain
-    VNL_FOR(i, m.nv) s[L.LD + madr(i)] += m.dof_armature[i] + diag_scale * m.dof_damping[i];
+    VNL_FOR(i, MI(nv)) s[LO(LD) + madr(i)] += m.dof_armature[i] + diag_scale * m.dof_damping[i];
     VNL_SYNC();
-    if (m.solver_newton && diag_scale == vreal(0.)) {  // dense symmetric copy of qM: the Newton solver's Hessian and M * search
-      const int nv = m.nv;
-      VNL_FOR(k, nv * nv) s[L.newt_M + k] = vreal(0.);
+    if (MI(solver_newton) && diag_scale == vreal(0.)) {  // dense symmetric copy of qM: the Newton solver's Hessian and M * search
+      const int nv = MI(nv);
+      VNL_FOR(k, nv * nv) s[LO(newt_M) + k] = vreal(0.);
       VNL_SYNC();
-      VNL_FOR(e, m.nM) {
+      VNL_FOR(e, MI(nM)) {
         const int i = m.M_row[e], j = anc_of(e);
-        const vreal v = s[L.LD + e];
-        s[L.newt_M + i * nv + j] = v, s[L.newt_M + j * nv + i] = v;
+        const vreal v = s[LO(LD) + e];
+        s[LO(newt_M) + i * nv + j] = v, s[LO(newt_M) + j * nv + i] = v;
       }
       VNL_SYNC();
     }
@@ -626,16 +631,16 @@ struct EnvWave {
     // (A column-per-lane variant that keeps the pivot row in registers and broadcasts it with
     // v_readlane was measured 2x slower: one LDS round trip in flight per step.  What matters is the
     // number of independent LDS accesses in flight, so each lane streams one ancestor row, 8-wide.)
-    for (int k = m.nv - 1; k >= 0; k--) {
+    for (int k = MI(nv) - 1; k >= 0; k--) {
       int adr_k = madr(k), dk = eadr(k) - adr_k;
-      vreal inv = vreal(1.) / s[L.LD + adr_k];
-      VNL_SERIAL { s[L.dinv + k] = inv; }
+      vreal inv = vreal(1.) / s[LO(LD) + adr_k];
+      VNL_SERIAL { s[LO(dinv) + k] = inv; }
       if (dk == 0) continue;
       VNL_FOR(a1, dk) {  // one lane per ancestor row: row(anc_a)[0..len) -= tmp * row_k[a .. a+len)
         int a = a1 + 1, len = dk - a + 1;
-        vreal tmp = s[L.LD + adr_k + a] * inv;
-        const vreal* src = s + L.LD + adr_k + a;
-        vreal* dst = s + L.LD + madr(anc_of(adr_k + a));
+        vreal tmp = s[LO(LD) + adr_k + a] * inv;
+        const vreal* src = s + LO(LD) + adr_k + a;
+        vreal* dst = s + LO(LD) + madr(anc_of(adr_k + a));
         int c = 0;
         for (; c + 8 <= len; c += 8) {  // all 16 loads of a trip are issued before the first store
           vreal x0 = src[c], x1 = src[c + 1], x2 = src[c + 2], x3 = src[c + 3];
@@ -655,10 +660,10 @@ struct EnvWave {
       VNL_SYNC();
     }
     VNL_SYNC();
-    VNL_FOR(i, m.nv) {
+    VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal di = s[L.dinv + i];
-      for (int t = 1; t <= dep; t++) s[L.LD + adr + t] *= di;
+      vreal di = s[LO(dinv) + i];
+      for (int t = 1; t <= dep; t++) s[LO(LD) + adr + t] *= di;
     }
     VNL_SYNC();
   }
@@ -668,9 +673,9 @@ struct EnvWave {
   // row.  Per level: (A) stage the row base addresses of the ancestors, (B) all entries of the level
   // in parallel into a staging buffer, (C) write back.
   VNL_HD void invert_factor_lds() const {
-    int stage = L.Ma;              // Ma|grad free while factorising
-    int* base = (int*)(s + L.Mgrad);  // Mgrad|search likewise
-    for (int lev = 1; lev <= m.max_depth; lev++) {
+    int stage = LO(Ma);              // Ma|grad free while factorising
+    int* base = (int*)(s + LO(Mgrad));  // Mgrad|search likewise
+    for (int lev = 1; lev <= MI(max_depth); lev++) {
       int q0 = lvl_start(lev), nrow = lvl_start(lev + 1) - q0, n = nrow * lev;
       VNL_FOR(q, n) {
         int i = lvl_dof(q0 + q / lev), t = q % lev + 1;
@@ -681,9 +686,9 @@ struct EnvWave {
         int rr = q / lev, i = lvl_dof(q0 + rr), t = q - rr * lev + 1;
         int adr = madr(i);
         const int* bb = base + rr * lev - 1;  // bb[u] = madr(anc_u(i))
-        vreal acc = -s[L.LD + adr + t];
-        const vreal* row = s + L.LD + adr;
-        const vreal* ld = s + L.LD + t;
+        vreal acc = -s[LO(LD) + adr + t];
+        const vreal* row = s + LO(LD) + adr;
+        const vreal* ld = s + LO(LD) + t;
         int u = 1;
         for (; u + 8 <= t; u += 8) {
           int b0 = bb[u], b1 = bb[u + 1], b2 = bb[u + 2], b3 = bb[u + 3];
@@ -706,7 +711,7 @@ struct EnvWave {
       VNL_SYNC();
       VNL_FOR(q, n) {
         int rr = q / lev, i = lvl_dof(q0 + rr), t = q - rr * lev + 1;
-        s[L.LD + madr(i) + t] = s[stage + q];
+        s[LO(LD) + madr(i) + t] = s[stage + q];
       }
       VNL_SYNC();
     }
@@ -760,17 +765,17 @@ struct EnvWave {
     auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
     vreal rr[NSET][MAXD], dg[NSET];
     int dep[NSET], last[NSET];
-    const int sc = (L.Ma + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; VNL_FAC_LINES * (MAXD + 4) floats
+    const int sc = (LO(Ma) + 3) & ~3;  // Ma|grad|Mgrad|search are dead while factorising; VNL_FAC_LINES * (MAXD + 4) floats
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      bool ok = a < m.nv;
+      bool ok = a < MI(nv);
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
       dep[q] = d, last[q] = ok ? a + ndesc(a) : -1;
-      dg[q] = ok ? s[L.LD + adr] : vreal(1.);
+      dg[q] = ok ? s[LO(LD) + adr] : vreal(1.);
 #pragma unroll
       for (int c = 0; c < MAXD; c++)
-        if (c < qd(q)) rr[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
+        if (c < qd(q)) rr[q][c] = c < d ? s[LO(LD) + adr + d - c] : vreal(0.);
     }
     // Schedule (host, build_dev_model): row j is the pivot of step dof_ftime[j], after all of its
     // descendants; rows with disjoint subtrees share a step, each with its own scratch line
@@ -781,13 +786,13 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      fpack[q] = a < m.nv ? m.dof_fslot[a] : 0;
-      ftime[q] = a < m.nv ? m.dof_ftime[a] : -1;
-      bb[q] = (SOLVE && a < m.nv) ? s[rhs + a] : vreal(0.), myinv[q] = vreal(0.);
+      fpack[q] = a < MI(nv) ? m.dof_fslot[a] : 0;
+      ftime[q] = a < MI(nv) ? m.dof_ftime[a] : -1;
+      bb[q] = (SOLVE && a < MI(nv)) ? s[rhs + a] : vreal(0.), myinv[q] = vreal(0.);
     }
     VNL_SYNC();
     VNL_PROF(7);
-    const int nsteps = with_loop ? m.fac_steps : 0;  // (false: diagnostic pricing of the load / store phases only)
+    const int nsteps = with_loop ? MI(fac_steps) : 0;  // (false: diagnostic pricing of the load / store phases only)
     for (int step = 0; step < nsteps; step++) {
       int npub = 0;
 #pragma unroll
@@ -811,7 +816,7 @@ struct EnvWave {
             s[line + MAXD + 2] = bb[q];
             myinv[q] = inv;
           } else {
-            s[L.dinv + a] = inv;
+            s[LO(dinv) + a] = inv;
           }
         }
       }
@@ -885,11 +890,11 @@ struct EnvWave {
       for (int q = 0; q < NSET; q++) acc[q] = bb[q] * myinv[q];  // D^-1 w
 #pragma unroll
       for (int c = 0; c < MAXD; c++) {
-        if (c <= m.max_depth) {
+        if (c <= MI(max_depth)) {
 #pragma unroll
           for (int q = 0; q < NSET; q++) {
             int a = (int)lane + q * VNL_LANES;
-            if (a < m.nv && dep[q] == c) {  // final: all ancestor terms are in
+            if (a < MI(nv) && dep[q] == c) {  // final: all ancestor terms are in
               s[rhs + a] = acc[q];
               for (int mk = fpack[q] >> 16; mk != 0; mk &= mk - 1) s[xs + __builtin_ctz(mk) * MAXD + c] = acc[q];
             }
@@ -908,13 +913,13 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      if (a < m.nv) {
+      if (a < MI(nv)) {
         int adr = madr(a), d = dep[q];
-        vreal di = s[L.dinv + a];
-        s[L.LD + adr] = dg[q];
+        vreal di = s[LO(dinv) + a];
+        s[LO(LD) + adr] = dg[q];
 #pragma unroll
         for (int c = 0; c < MAXD; c++)
-          if (c < qd(q) && c < d) s[L.LD + adr + d - c] = rr[q][c] * di;
+          if (c < qd(q) && c < d) s[LO(LD) + adr + d - c] = rr[q][c] * di;
       }
     }
     VNL_SYNC();
@@ -933,7 +938,7 @@ struct EnvWave {
     for (int q = NSET - 1; q >= 0; q--) {
       vreal nn[MAXD];
       int a = (int)lane + q * VNL_LANES;
-      bool ok = a < m.nv;
+      bool ok = a < MI(nv);
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
       int own = LDb + adr;
       const vreal* pb[MAXD];  // row of the u-th ancestor (rows past the depth alias row 0: read, never used)
@@ -963,7 +968,7 @@ struct EnvWave {
   // The TWO factorisations of a substep in ONE pass: forward.euler's implicit damping needs M + h diag(damping), the
   // solver needs M, both from the same qpos.  Their rows sit side by side in registers and go through the same
   // scheduled elimination (one dependent chain of LDS round trips instead of two, the second system's updates fill the
-  // first one's waits); the mass matrix is built once.  System 1 ends in L.LD / L.dinv as factor_rows leaves it;
+  // first one's waits); the mass matrix is built once.  System 1 ends in LO(LD) / LO(dinv) as factor_rows leaves it;
   // system 2 (unit-lower rows scaled by 1/D, then 1/D) goes to this env's global scratch `g2` [nM + nv] and is
   // brought back by euler() once the solver has released the pool.
   // Which published pivots row a must absorb in which step is static per model: m.fac_match[a][step] (one bit per
@@ -977,27 +982,27 @@ struct EnvWave {
     vreal r1[NSET][MAXD], r2[NSET][MAXD], d1[NSET], d2[NSET], inv1[NSET], inv2[NSET];
     int dep[NSET], ftime[NSET], myline[NSET];
     const unsigned char* mt[NSET];
-    const int sc = (L.Ma + 3) & ~3, sc2 = sc + VNL_FAC_LINES * LW;  // Ma .. tmp2 are dead while factorising
-    const int nsteps = m.fac_steps;
+    const int sc = (LO(Ma) + 3) & ~3, sc2 = sc + VNL_FAC_LINES * LW;  // Ma .. tmp2 are dead while factorising
+    const int nsteps = MI(fac_steps);
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      bool ok = a < m.nv;
+      bool ok = a < MI(nv);
       int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
       dep[q] = d;
-      d1[q] = ok ? s[L.LD + adr] : vreal(1.);
+      d1[q] = ok ? s[LO(LD) + adr] : vreal(1.);
       d2[q] = ok ? d1[q] + h * m.dof_damping[a] : vreal(1.);
       inv1[q] = inv2[q] = vreal(0.);
 #pragma unroll
       for (int c = 0; c < MAXD; c++)
-        if (c < qd(q)) r1[q][c] = r2[q][c] = c < d ? s[L.LD + adr + d - c] : vreal(0.);
+        if (c < qd(q)) r1[q][c] = r2[q][c] = c < d ? s[LO(LD) + adr + d - c] : vreal(0.);
       myline[q] = ok ? (m.dof_fslot[a] & 0xff) : 0;
       ftime[q] = ok ? m.dof_ftime[a] : -1;
       mt[q] = m.fac_match + (size_t)(ok ? a : 0) * nsteps;
     }
     unsigned nxt[NSET];
 #pragma unroll
-    for (int q = 0; q < NSET; q++) nxt[q] = ((int)lane + q * VNL_LANES < m.nv && nsteps > 0) ? mt[q][0] : 0u;
+    for (int q = 0; q < NSET; q++) nxt[q] = ((int)lane + q * VNL_LANES < MI(nv) && nsteps > 0) ? mt[q][0] : 0u;
     VNL_SYNC();
     VNL_PROF(7);
     for (int step = 0; step < nsteps; step++) {
@@ -1005,7 +1010,7 @@ struct EnvWave {
 #pragma unroll
       for (int q = 0; q < NSET; q++) {
         cur[q] = nxt[q];
-        nxt[q] = ((int)lane + q * VNL_LANES < m.nv && step + 1 < nsteps) ? mt[q][step + 1] : 0u;  // prefetch
+        nxt[q] = ((int)lane + q * VNL_LANES < MI(nv) && step + 1 < nsteps) ? mt[q][step + 1] : 0u;  // prefetch
         if (ftime[q] == step) {
           const int l1 = sc + myline[q] * LW, l2 = sc2 + myline[q] * LW, a = (int)lane + q * VNL_LANES;
 #pragma unroll
@@ -1075,7 +1080,7 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       int a = (int)lane + q * VNL_LANES;
-      if (a < m.nv) {  // the interleaved image mass_mul_pair / invert_pair read (see the packed form below)
+      if (a < MI(nv)) {  // the interleaved image mass_mul_pair / invert_pair read (see the packed form below)
         const int adr = madr(a), d = dep[q], R2 = pair_base(), DV = pair_dinv();
         s[R2 + 2 * adr] = d1[q], s[R2 + 2 * adr + 1] = d2[q];
         s[DV + 2 * a] = inv1[q], s[DV + 2 * a + 1] = inv2[q];
@@ -1105,25 +1110,25 @@ struct EnvWave {
     static_assert(!GUESTS || NCH == 3, "guest rows sit in chunks 1-2 of 3");
     constexpr int LW = 2 * MAXD + 4;  // [(r1, r2) x MAXD | 1/pivot1, 1/pivot2 | pad]
     v2r rr[MAXD];
-    const int sc = (L.Ma + 3) & ~3;  // Ma .. tmp2 are dead while factorising
-    const int nsteps = m.fac_steps;
+    const int sc = (LO(Ma) + 3) & ~3;  // Ma .. tmp2 are dead while factorising
+    const int nsteps = MI(fac_steps);
     // row A = this lane's own row; row B = its guest (or none)
     const int a = (int)lane, g = GUESTS ? m.fac_guest[lane] : -1;
-    const bool okA = a < m.nv, hasB = g >= 0;
+    const bool okA = a < MI(nv), hasB = g >= 0;
     const int adrA = okA ? madr(a) : 0, depA = okA ? eadr(a) - adrA : 0;
     const int adrB = hasB ? madr(g) : 0, depB = hasB ? eadr(g) - adrB : 0;
     v2r dgA, dgB, ivA, ivB;  // diagonals of both systems; iv = their reciprocals once the row was a pivot
     {
-      const vreal d1 = okA ? s[L.LD + adrA] : vreal(1.);
+      const vreal d1 = okA ? s[LO(LD) + adrA] : vreal(1.);
       dgA = v2r{d1, okA ? d1 + h * m.dof_damping[a] : vreal(1.)};
-      const vreal e1 = hasB ? s[L.LD + adrB] : vreal(1.);
+      const vreal e1 = hasB ? s[LO(LD) + adrB] : vreal(1.);
       dgB = v2r{e1, hasB ? e1 + h * m.dof_damping[hasB ? g : 0] : vreal(1.)};
       ivA = ivB = v2r{vreal(0.), vreal(0.)};
     }
 #pragma unroll
     for (int c = 0; c < MAXD; c++) {
-      vreal x = c < depA ? s[L.LD + adrA + depA - c] : vreal(0.);
-      if (GUESTS && c >= CH && hasB) x = c - CH < depB ? s[L.LD + adrB + depB - (c - CH)] : vreal(0.);
+      vreal x = c < depA ? s[LO(LD) + adrA + depA - c] : vreal(0.);
+      if (GUESTS && c >= CH && hasB) x = c - CH < depB ? s[LO(LD) + adrB + depB - (c - CH)] : vreal(0.);
       rr[c] = v2r{x, x};
     }
     const int lineA = okA ? (m.dof_fslot[a] & 0xff) : 0, lineB = hasB ? (m.dof_fslot[g] & 0xff) : 0;
@@ -1249,18 +1254,18 @@ struct EnvWave {
   // models whose two factorisations go through factor_pair (same conditions as the register route of factor(), plus
   // room for the second set of scratch lines in the eight dead vectors Ma .. tmp2 and for the factor copy in the pool)
   VNL_HD bool factor_pair_ok() const {
-    const int nv = m.nv, md = m.max_depth;
-    if (!m.eulerdamp || !m.fac_match) return false;
+    const int nv = MI(nv), md = MI(max_depth);
+    if (!MI(eulerdamp) || !m.fac_match) return false;
     const int room = 8 * nv - 3 - 8 * VNL_FAC_LINES;
     const bool regs = (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) ||
-                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16 && m.fac_guest);
+                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (MI(fac_nleaf) >> 8) < 16 && m.fac_guest);
     // (m.fac_guest: the rows 64.. have a place in the packed device form; a model where they have none takes the
     // one-system route in both builds, so that the two forms of factor_pair always run on the same models)
-    // .. and the interleaved image of both factors (2 nM elements from L.LD on) ends below cvel, which make_constraint still needs
-    return regs && 2 * m.nM <= L.pair_room && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
+    // .. and the interleaved image of both factors (2 nM elements from LO(LD) on) ends below cvel, which make_constraint still needs
+    return regs && 2 * MI(nM) <= LO(pair_room) && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
   }
   VNL_HD void factor_both(vreal h) const {
-    const int nv = m.nv, md = m.max_depth;
+    const int nv = MI(nv), md = MI(max_depth);
 #ifdef VNL_FAC_PACKED
     if (nv <= VNL_LANES && md < 16) return factor_pair_packed<16, false>(h);
     if (nv <= VNL_LANES) return factor_pair_packed<36, false>(h);
@@ -1273,12 +1278,12 @@ struct EnvWave {
   }
 
   VNL_HD void factor(bool with_loop = true) const {
-    const int nv = m.nv, md = m.max_depth;
+    const int nv = MI(nv), md = MI(max_depth);
     // the scratch lines of factor_rows live in the four dead CG vectors (Ma .. search)
     const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16>(with_loop);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36>(with_loop);
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (m.fac_nleaf >> 8) < 16)
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (MI(fac_nleaf) >> 8) < 16)
       factor_rows<VNL_ROWSETS_2, 36, false, 16>(with_loop);  // (a second lane set with deeper rows takes the LDS route:
                                                              // every instantiation costs registers for the whole kernel)
     else factor_lds();
@@ -1286,31 +1291,31 @@ struct EnvWave {
   // solve (matrix in LD) x = s[rhs .. rhs+nv) in place without storing a factor; false if this model needs the
   // general route (factor + invert_factor + solve_inplace)
   VNL_HD bool factor_solve(int rhs) const {
-    const int nv = m.nv, md = m.max_depth;
+    const int nv = MI(nv), md = MI(max_depth);
     const int room = 4 * nv - 3 - 4 * VNL_FAC_LINES;
-    if ((m.fac_nleaf & 0xff) == 0) return false;
+    if ((MI(fac_nleaf) & 0xff) == 0) return false;
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16 && VNL_FAC_LINES * 16 <= room) factor_rows<VNL_ROWSETS_1, 16, true>(true, rhs);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room) factor_rows<VNL_ROWSETS_1, 36, true>(true, rhs);
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (m.fac_nleaf >> 8) < 16)
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && VNL_FAC_LINES * 36 <= room && (MI(fac_nleaf) >> 8) < 16)
       factor_rows<VNL_ROWSETS_2, 36, true, 16>(true, rhs);
     else return false;
     return true;
   }
-  // (LDb: where the factor sits -- L.LD, or the copy of the second factor that euler() brings into the pool)
+  // (LDb: where the factor sits -- LO(LD), or the copy of the second factor that euler() brings into the pool)
   VNL_HD void invert_factor(int LDb) const {
-    const int nv = m.nv, md = m.max_depth;
+    const int nv = MI(nv), md = MI(max_depth);
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_rows<VNL_ROWSETS_1, 16>(LDb);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) invert_rows<VNL_ROWSETS_1, 36>(LDb);
-    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (m.fac_nleaf >> 8) < 16) invert_rows<VNL_ROWSETS_2, 36, 16>(LDb);
-    else invert_factor_lds();  // (only ever reached with LDb == L.LD: factor_pair_ok() excludes these models)
+    else if (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (MI(fac_nleaf) >> 8) < 16) invert_rows<VNL_ROWSETS_2, 36, 16>(LDb);
+    else invert_factor_lds();  // (only ever reached with LDb == LO(LD): factor_pair_ok() excludes these models)
   }
-  VNL_HD void invert_factor() const { invert_factor(L.LD); }
+  VNL_HD void invert_factor() const { invert_factor(LO(LD)); }
 
   // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
   // (ST: element stride of the factor -- 1, or 2 for system 1 of the interleaved pair that factor_pair leaves)
   template <int ST = 1>
   VNL_HD vreal row_dot(int adr, int dep, int in, int LDb) const {
-    const unsigned char* an = (const unsigned char*)(s + L.tab_anc) + adr;
+    const unsigned char* an = (const unsigned char*)(s + LO(tab_anc)) + adr;
     const vreal* row = s + LDb + ST * adr;
     vreal acc = vreal(0.);
     int t = 1;
@@ -1352,7 +1357,7 @@ struct EnvWave {
 
   // out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]   (A = strictly-lower part held in LD: L or L^-1)
   VNL_HD void row_apply(int in, int out, bool scale_by_dinv, int LDb, int dinvb) const {
-    VNL_FOR(i, m.nv) {
+    VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[in + i] + row_dot(adr, dep, in, LDb);
       s[out + i] = scale_by_dinv ? acc * s[dinvb + i] : acc;
@@ -1362,10 +1367,10 @@ struct EnvWave {
   // out[a] = (in[a] + sum_{i in desc(a)} A(i, a) in[i]) (* or / D); descendants are the next ndesc dofs
   template <int ST = 1>
   VNL_HD void col_apply(int in, int out, int dmode /*0 none, 1 multiply by dinv, 2 divide by dinv*/, int LDb, int dinvb) const {
-    VNL_FOR(a, m.nv) {
+    VNL_FOR(a, MI(nv)) {
       int da = eadr(a) - madr(a), nd = ndesc(a);
       vreal acc = s[in + a];
-      const unsigned short* ea = (const unsigned short*)(s + L.tab_madr) + m.nv;
+      const unsigned short* ea = (const unsigned short*)(s + LO(tab_madr)) + MI(nv);
       const vreal* ld = s + LDb - ST * da;
       int i = a + 1, iend = a + nd;
       constexpr int W = VNL_CHAIN_WIDTH;
@@ -1408,36 +1413,36 @@ struct EnvWave {
 
   // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
   VNL_HD void solve_inplace(int x, int LDb, int dinvb) const {
-    col_apply(x, L.tmp2, 1, LDb, dinvb);
-    row_apply(L.tmp2, x, false, LDb, dinvb);
+    col_apply(x, LO(tmp2), 1, LDb, dinvb);
+    row_apply(LO(tmp2), x, false, LDb, dinvb);
   }
-  VNL_HD void solve_inplace(int x) const { solve_inplace(x, L.LD, L.dinv); }
+  VNL_HD void solve_inplace(int x) const { solve_inplace(x, LO(LD), LO(dinv)); }
 
   // out = M v = L' D L v with the (not yet inverted) factor
   VNL_HD void mass_mul_factor(int vec, int out) const {
-    VNL_FOR(i, m.nv) {
+    VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[vec + i] + row_dot(adr, dep, vec, L.LD);
-      s[L.tmp2 + i] = acc / s[L.dinv + i];
+      vreal acc = s[vec + i] + row_dot(adr, dep, vec, LO(LD));
+      s[LO(tmp2) + i] = acc / s[LO(dinv) + i];
     }
     VNL_SYNC();
-    col_apply(L.tmp2, out, 0, L.LD, L.dinv);
+    col_apply(LO(tmp2), out, 0, LO(LD), LO(dinv));
   }
 
   // out = M v from system 1 of the INTERLEAVED pair factor_pair leaves: (L1, L2) entry pairs at R2 + 2 k, (1/D1, 1/D2) at DV + 2 a
   VNL_HD void mass_mul_pair(int vec, int out, int R2, int DV) const {
-    VNL_FOR(i, m.nv) {
+    VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[vec + i] + row_dot<2>(adr, dep, vec, R2);
-      s[L.tmp2 + i] = acc / s[DV + 2 * i];
+      s[LO(tmp2) + i] = acc / s[DV + 2 * i];
     }
     VNL_SYNC();
-    col_apply<2>(L.tmp2, out, 0, R2, DV);
+    col_apply<2>(LO(tmp2), out, 0, R2, DV);
   }
 
   // BOTH factors of a substep inverted in ONE pass (same recursion as invert_rows, the two systems side by side: one packed
   // multiply-add and one 8-byte LDS read per entry pair instead of two inversions -- the second one used to run in euler()).
-  // In: the interleaved pair at R2 / DV.  Out: N1 = L1^-1 in L.LD and 1/D1 in L.dinv, as every M^-1 product expects them;
+  // In: the interleaved pair at R2 / DV.  Out: N1 = L1^-1 in LO(LD) and 1/D1 in LO(dinv), as every M^-1 product expects them;
   // N2 and 1/D2 in the env's global scratch g2 [nM + nv], which euler() brings back once the solver has released the pool.
   // All reads come before the one barrier, all writes after it (the outputs overlap the interleaved input).
   template <int NSET, int MAXD, int MAXD1 = MAXD>
@@ -1448,7 +1453,7 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       const int a = (int)lane + q * VNL_LANES;
-      const bool ok = a < m.nv;
+      const bool ok = a < MI(nv);
       const int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
       adrs[q] = adr, deps[q] = d;
       const vreal* own = s + R2 + 2 * adr;
@@ -1462,7 +1467,7 @@ struct EnvWave {
         if (t < qd(q) && vnl_wave_any(t <= d)) {
           // the operands of entry t are fetched XB pairs at a time before their (dependent) multiply-add chain: all of
           // them at once (invert_rows) would need 2 x 35 registers here
-          constexpr int XB = 12;
+          constexpr int XB = 8;
           v2r acc = t <= d ? v2r{-own[2 * t], -own[2 * t + 1]} : v2r{vreal(0.), vreal(0.)};
 #pragma unroll
           for (int u0 = 1; u0 < t; u0 += XB) {
@@ -1482,72 +1487,72 @@ struct EnvWave {
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       const int a = (int)lane + q * VNL_LANES;
-      dv[q] = a < m.nv ? v2r{s[DV + 2 * a], s[DV + 2 * a + 1]} : v2r{vreal(0.), vreal(0.)};
+      dv[q] = a < MI(nv) ? v2r{s[DV + 2 * a], s[DV + 2 * a + 1]} : v2r{vreal(0.), vreal(0.)};
     }
     VNL_SYNC();
 #pragma unroll
     for (int q = 0; q < NSET; q++) {
       const int a = (int)lane + q * VNL_LANES;
-      if (a < m.nv) {
+      if (a < MI(nv)) {
         const int adr = adrs[q], d = deps[q];
-        s[L.LD + adr] = dg[q][0], g2[adr] = dg[q][1];
-        s[L.dinv + a] = dv[q][0], g2[m.nM + a] = dv[q][1];
+        s[LO(LD) + adr] = dg[q][0], g2[adr] = dg[q][1];
+        s[LO(dinv) + a] = dv[q][0], g2[MI(nM) + a] = dv[q][1];
 #pragma unroll
         for (int t = 1; t < MAXD; t++)
-          if (t < qd(q) && t <= d) s[L.LD + adr + t] = nn[q][t][0], g2[adr + t] = nn[q][t][1];
+          if (t < qd(q) && t <= d) s[LO(LD) + adr + t] = nn[q][t][0], g2[adr + t] = nn[q][t][1];
       }
     }
     VNL_SYNC();
   }
   VNL_HD void invert_both(int R2, int DV, vreal* g2) const {
-    const int nv = m.nv, md = m.max_depth;
+    const int nv = MI(nv), md = MI(max_depth);
     if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_pair<VNL_ROWSETS_1, 16>(R2, DV, g2);
     else if (nv <= VNL_ROWSETS_1 * VNL_LANES) invert_pair<VNL_ROWSETS_1, 36>(R2, DV, g2);
     else invert_pair<VNL_ROWSETS_2, 36, 16>(R2, DV, g2);
   }
-  // where factor_pair leaves the interleaved pair: from L.LD on (through L.dinv into the pool, below cvel), and the pair of
+  // where factor_pair leaves the interleaved pair: from LO(LD) on (through LO(dinv) into the pool, below cvel), and the pair of
   // reciprocal pivots in the first two of the eight CG vectors (dead until the solver starts)
-  VNL_HD int pair_base() const { return L.LD; }
-  VNL_HD int pair_dinv() const { return L.Ma; }
+  VNL_HD int pair_base() const { return LO(LD); }
+  VNL_HD int pair_dinv() const { return LO(Ma); }
 
   // ------------------------------------------------------------------ velocity
-  // com_vel + rne: -qfrc_bias - damping*qvel -> L.smooth.  Body velocities / accelerations are tree prefixes
+  // com_vel + rne: -qfrc_bias - damping*qvel -> LO(smooth).  Body velocities / accelerations are tree prefixes
   // (pointer jumping) of per-body contributions; returns the LDS offset of cvel (kept for
   // make_constraint).  Needs cinert in T1.
   VNL_HD int bias_forces() const {
-    int nb6 = 6 * m.nbody;
-    int X0 = L.P + 10 * m.nbody, X1 = X0 + nb6;  // after cinert; cvel has to end in X1 (X0 is reused)
+    int nb6 = 6 * MI(nbody);
+    int X0 = LO(P) + 10 * MI(nbody), X1 = X0 + nb6;  // after cinert; cvel has to end in X1 (X0 is reused)
     // cvel[b] = sum of cdof_d qvel_d over the dofs on b's path: differences of the dof prefix sums (parked in the
     // factor buffer, which is free until the mass matrix is built)
-    dof_prefix(L.qvel, L.LD);
+    dof_prefix(LO(qvel), LO(LD));
     const int cv = X1;
-    VNL_FOR(b, m.nbody) st6(cv + 6 * b, path_sum(L.LD, m.body_pathseg + 8 * b));
+    VNL_FOR(b, MI(nbody)) st6(cv + 6 * b, path_sum(LO(LD), m.body_pathseg + 8 * b));
     VNL_SYNC();
     VNL_PROF(2);
     int ca = X0;
     // own acceleration term of every body (sum over its dofs of cdof_dot * qvel), prefix-summed over the body index
     // in the same pass; cacc[b] = sum over b's ancestors = differences over its runs of consecutive ancestor bodies
-    const int QB = L.LD + 6 * (m.nv + 1);
+    const int QB = LO(LD) + 6 * (MI(nv) + 1);
     S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
-    VNL_FOR(b, VNL_PAD_ITEMS(m.nbody)) {
+    VNL_FOR(b, VNL_PAD_ITEMS(MI(nbody))) {
       S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      if (b > 0 && b < m.nbody) {
+      if (b > 0 && b < MI(nbody)) {
         S6 vel = ld6(cv + 6 * parent_of(b));
         int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
         for (int k = 0; k < jn; k++) {
           int j = ja + k, da = m.jnt_dofadr[j];
           if (m.jnt_type[j] == VNL_JNT_FREE) {
-            for (int t = 0; t < 3; t++) vel = vel + ld6(L.cdof + 6 * (da + t)) * s[L.qvel + da + t];
+            for (int t = 0; t < 3; t++) vel = vel + ld6(LO(cdof) + 6 * (da + t)) * s[LO(qvel) + da + t];
             S6 vel0 = vel;
             for (int t = 3; t < 6; t++) {
-              S6 c = ld6(L.cdof + 6 * (da + t));
-              vreal qd = s[L.qvel + da + t];
+              S6 c = ld6(LO(cdof) + 6 * (da + t));
+              vreal qd = s[LO(qvel) + da + t];
               acc = acc + mcross(vel0, c) * qd;
               vel = vel + c * qd;
             }
           } else {
-            S6 c = ld6(L.cdof + 6 * da);
-            vreal qd = s[L.qvel + da];
+            S6 c = ld6(LO(cdof) + 6 * da);
+            vreal qd = s[LO(qvel) + da];
             acc = acc + mcross(vel, c) * qd;
             vel = vel + c * qd;
           }
@@ -1556,27 +1561,27 @@ struct EnvWave {
       VNL_SCAN_ADD_C(acc.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(acc.a.y, run.a.y, carry.a.y);
       VNL_SCAN_ADD_C(acc.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(acc.l.x, run.l.x, carry.l.x);
       VNL_SCAN_ADD_C(acc.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(acc.l.z, run.l.z, carry.l.z);
-      if (b < m.nbody) st6(QB + 6 * (b + 1), acc);
+      if (b < MI(nbody)) st6(QB + 6 * (b + 1), acc);
       if (b == 0) st6(QB, S6{v3(0, 0, 0), v3(0, 0, 0)});
     }
     VNL_SYNC();
-    VNL_FOR(b, m.nbody) st6(ca + 6 * b, path_sum(QB, m.body_pathseg + 8 * b + 4));
+    VNL_FOR(b, MI(nbody)) st6(ca + 6 * b, path_sum(QB, m.body_pathseg + 8 * b + 4));
     VNL_SYNC();
     VNL_PROF(3);
-    VNL_FOR(b, m.nbody) {  // cfrc overwrites cacc in place (each body only needs its own entries)
+    VNL_FOR(b, MI(nbody)) {  // cfrc overwrites cacc in place (each body only needs its own entries)
       if (b == 0) {
         st6(ca, S6{v3(0, 0, 0), v3(0, 0, 0)});
         continue;
       }
       S6 vel = ld6(cv + 6 * b), acc = ld6(ca + 6 * b);
       acc.l = acc.l + v3(-m.gx, -m.gy, -m.gz);  // cacc of the world body, inherited by every body
-      st6(ca + 6 * b, inert_mul(L.P + 10 * b, acc) + mcross_force(vel, inert_mul(L.P + 10 * b, vel)));
+      st6(ca + 6 * b, inert_mul(LO(P) + 10 * b, acc) + mcross_force(vel, inert_mul(LO(P) + 10 * b, vel)));
     }
     VNL_SYNC();
     tree_accumulate(ca, 6);
     // qfrc_smooth starts as passive damping minus the bias force (springs / actuation added by smooth_forces)
-    VNL_FOR(d, m.nv)
-      s[L.smooth + d] = -m.dof_damping[d] * s[L.qvel + d] - dot(ld6(L.cdof + 6 * d), ld6(ca + 6 * m.dof_body[d]));
+    VNL_FOR(d, MI(nv))
+      s[LO(smooth) + d] = -m.dof_damping[d] * s[LO(qvel) + d] - dot(ld6(LO(cdof) + 6 * d), ld6(ca + 6 * m.dof_body[d]));
     VNL_SYNC();
     VNL_PROF(4);
     return cv;
@@ -1584,31 +1589,31 @@ struct EnvWave {
 
   // passive + actuation + qfrc_smooth + qacc_smooth
   VNL_HD void smooth_forces() const {
-    VNL_FOR(j, m.njnt) {
+    VNL_FOR(j, MI(njnt)) {
       if (m.jnt_type[j] == VNL_JNT_HINGE) {
         vreal k = m.jnt_stiffness[j];
-        if (k != vreal(0.)) s[L.smooth + m.jnt_dofadr[j]] -= k * (s[L.qpos + m.jnt_qposadr[j]] - m.jnt_springref[j]);
+        if (k != vreal(0.)) s[LO(smooth) + m.jnt_dofadr[j]] -= k * (s[LO(qpos) + m.jnt_qposadr[j]] - m.jnt_springref[j]);
       }
     }
     // Actuator forces in parallel (the model tables are L2 reads: the former one-lane loop paid 30 latencies in a
     // row).  Several actuators may drive one dof, so each dof's lane then walks the actuator list in order and
     // keeps the forces aimed at it: broadcast LDS reads that pipeline, where one lane adding into the dofs paid a
     // dependent read-modify-write per actuator.
-    const int frc = L.tmp2, adof = L.tmp;  // both free here
+    const int frc = LO(tmp2), adof = LO(tmp);  // both free here
     const bool listed = m.dof_act != nullptr;  // (host table: the <= 4 actuators of every dof, in actuator order)
-    VNL_FOR(i, m.nu) {
-      vreal ctrl = s[L.ctrl + i], a = ctrl;
+    VNL_FOR(i, MI(nu)) {
+      vreal ctrl = s[LO(ctrl) + i], a = ctrl;
       vreal tau = m.act_tau[i];
       if (tau >= vreal(0.)) {
-        a = s[L.act + i];
-        s[L.actdot + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
+        a = s[LO(act) + i];
+        s[LO(actdot) + i] = (ctrl - a) / fmax(tau, VNL_MINVAL);
       }
       s[frc + i] = m.act_gear[i] * m.act_gain[i] * a;
       if (!listed) s[adof + i] = vreal(m.act_dof[i]);  // exact: dof < 2^24
     }
     VNL_SYNC();
     vreal* gf = gqfrc_act();
-    VNL_FOR(d, m.nv) {
+    VNL_FOR(d, MI(nv)) {
       vreal fa = vreal(0.);
       if (listed) {
         // the actuators aimed at this dof, packed by the host (index + 1 per byte, ascending: the same summation order as
@@ -1617,18 +1622,18 @@ struct EnvWave {
       } else {
         const vreal me = vreal(d);
 #pragma unroll 6
-        for (int i = 0; i < m.nu; i++) {
+        for (int i = 0; i < MI(nu); i++) {
           const vreal f = s[frc + i];
           if (s[adof + i] == me) fa += f;
         }
       }
       gf[d] = fa;
-      vreal v = s[L.smooth + d] + fa;
-      s[L.smooth + d] = v;
-      s[L.qacc_smooth + d] = v;
+      vreal v = s[LO(smooth) + d] + fa;
+      s[LO(smooth) + d] = v;
+      s[LO(qacc_smooth) + d] = v;
     }
     VNL_SYNC();
-    solve_inplace(L.qacc_smooth);
+    solve_inplace(LO(qacc_smooth));
   }
 
   // ------------------------------------------------------------------ constraints
@@ -1662,8 +1667,8 @@ struct EnvWave {
   VNL_HD void make_constraint(int cvel) const {
     V3 O = ref_point();
     V3 n = v3(m.pnx, m.pny, m.pnz), pp = v3(m.ppx, m.ppy, m.ppz);
-    VNL_FOR(r, m.nlimit) {
-      vreal q = s[L.qpos + m.lim_qadr[r]];
+    VNL_FOR(r, MI(nlimit)) {
+      vreal q = s[LO(qpos) + m.lim_qadr[r]];
       vreal dlo = q - m.lim_lo[r], dhi = m.lim_hi[r] - q;
       vreal pos = fmin(dlo, dhi) - m.lim_margin[r];
       vreal sign = dlo < dhi ? vreal(1.) : vreal(-1.);
@@ -1671,10 +1676,10 @@ struct EnvWave {
       kbimp(m.lim_solref + 2 * r, m.lim_solimp + 5 * r, m.dt, pos, k, b, imp);
       vreal R = fmax(m.lim_invweight[r] * (vreal(1.) - imp) / imp, VNL_MINVAL);
       // the sign of the limit Jacobian (+1 lower / -1 upper side) rides on efc_D: D = 0 <=> row absent
-      s[L.efc_D + r] = pos < vreal(0.) ? sign / R : vreal(0.);
-      s[L.Jaref + r] = b * (sign * s[L.qvel + m.lim_dof[r]]) + k * imp * pos;  // -aref
+      s[LO(efc_D) + r] = pos < vreal(0.) ? sign / R : vreal(0.);
+      s[LO(Jaref) + r] = b * (sign * s[LO(qvel) + m.lim_dof[r]]) + k * imp * pos;  // -aref
     }
-    VNL_FOR(g, m.ncg) {
+    VNL_FOR(g, MI(ncg)) {
       int bd = m.cg_body[g], c0 = m.cg_conadr[g], type = m.cg_type[g];
       Q4 bq = gquat4(bd);
       V3 gpos = gpos3(bd) + qrot(t3(m.cg_pos, g), bq);
@@ -1714,12 +1719,12 @@ struct EnvWave {
       vreal mu = m.cg_mu[g], margin = m.cg_margin[g], invw = m.cg_invweight[g];
       S6 vel = ld6(cvel + 6 * bd);
       for (int q = 0; q < nc; q++) {
-        int c = c0 + q, r0 = m.nlimit + 4 * c;
+        int c = c0 + q, r0 = MI(nlimit) + 4 * c;
         vreal dist = q == 0 ? dist0 : dist1;
         V3 rel = (q == 0 ? cpos0 : cpos1) - O;
         vreal d = dist - margin;
-        st3(L.con_r + 3 * c, rel);
-        if (q == 0) st3(L.con_t1 + 3 * g, t1);
+        st3(LO(con_r) + 3 * c, rel);
+        if (q == 0) st3(LO(con_t1) + 3 * g, t1);
         vreal k, b, imp;
         kbimp(m.cg_solref + 2 * g, m.cg_solimp + 5 * g, m.dt, d, k, b, imp);
         vreal Rr = fmax(invw * (vreal(1.) - imp) / imp, VNL_MINVAL);
@@ -1727,35 +1732,35 @@ struct EnvWave {
         V3 pv = vel.l + cross(vel.a, rel);
         vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
         vreal kp = k * imp * d;
-        s[L.efc_D + r0] = D, s[L.efc_D + r0 + 1] = D, s[L.efc_D + r0 + 2] = D, s[L.efc_D + r0 + 3] = D;
-        s[L.Jaref + r0] = b * (jn + j1) + kp, s[L.Jaref + r0 + 1] = b * (jn - j1) + kp;  // -aref
-        s[L.Jaref + r0 + 2] = b * (jn + j2) + kp, s[L.Jaref + r0 + 3] = b * (jn - j2) + kp;
+        s[LO(efc_D) + r0] = D, s[LO(efc_D) + r0 + 1] = D, s[LO(efc_D) + r0 + 2] = D, s[LO(efc_D) + r0 + 3] = D;
+        s[LO(Jaref) + r0] = b * (jn + j1) + kp, s[LO(Jaref) + r0 + 1] = b * (jn - j1) + kp;  // -aref
+        s[LO(Jaref) + r0 + 2] = b * (jn + j2) + kp, s[LO(Jaref) + r0 + 3] = b * (jn - j2) + kp;
       }
     }
     VNL_SYNC();
     {  // list of contacts with D != 0 (typically a handful of the 59), in contact order
-      unsigned char* act = (unsigned char*)(s + L.act_list);
+      unsigned char* act = (unsigned char*)(s + LO(act_list));
       int na = 0;
-      VNL_FOR(c, VNL_PAD_ITEMS(m.ncon)) {
-        const bool on = c < m.ncon && s[L.efc_D + m.nlimit + 4 * (c < m.ncon ? c : 0)] != vreal(0.);
+      VNL_FOR(c, VNL_PAD_ITEMS(MI(ncon))) {
+        const bool on = c < MI(ncon) && s[LO(efc_D) + MI(nlimit) + 4 * (c < MI(ncon) ? c : 0)] != vreal(0.);
         int pos;
         VNL_RANK(on, na, pos);
         if (on) act[pos] = (unsigned char)c;
       }
-      VNL_SERIAL { ((int*)(s + L.act_list))[(m.ncon + 3) / 4] = na; }
+      VNL_SERIAL { ((int*)(s + LO(act_list)))[(MI(ncon) + 3) / 4] = na; }
     }
-    VNL_FOR(r, m.nefc) s[L.jv + r] = vreal(0.);  // rows of inactive contacts are never written again
+    VNL_FOR(r, MI(nefc)) s[LO(jv) + r] = vreal(0.);  // rows of inactive contacts are never written again
     {  // the rows that exist (D != 0: violated limits, the four pyramid rows of every active contact), in row order:
        // typically a few dozen of the 303, so the line search keeps ONE row per lane (line_search<1, compact>)
       unsigned short* lv = live_rows();
       int nl = 0;
-      VNL_FOR(r, VNL_PAD_ITEMS(m.nefc)) {
-        const bool on = r < m.nefc && s[L.efc_D + (r < m.nefc ? r : 0)] != vreal(0.);
+      VNL_FOR(r, VNL_PAD_ITEMS(MI(nefc))) {
+        const bool on = r < MI(nefc) && s[LO(efc_D) + (r < MI(nefc) ? r : 0)] != vreal(0.);
         int pos;
         VNL_RANK(on, nl, pos);
         if (on && pos < VNL_LIVE_MAX) lv[pos] = (unsigned short)r;
       }
-      VNL_SERIAL { ((int*)(s + L.act_list))[(m.ncon + 3) / 4 + 1] = nl; }
+      VNL_SERIAL { ((int*)(s + LO(act_list)))[(MI(ncon) + 3) / 4 + 1] = nl; }
     }
     VNL_SYNC();
     if (trace) {  // debug trace: which rows exist (the pre-solver discrete decisions)
@@ -1764,7 +1769,7 @@ struct EnvWave {
           int bits = 0;
           for (int b = 0; b < 32; b++) {
             const int r = 32 * w + b;
-            if (r < m.nefc && s[L.efc_D + r] != vreal(0.)) bits |= 1 << b;
+            if (r < MI(nefc) && s[LO(efc_D) + r] != vreal(0.)) bits |= 1 << b;
           }
           trace[VNL_TRACE_ROWS + w] = bits;
         }
@@ -1775,13 +1780,13 @@ struct EnvWave {
   // Q[k] = sum_{d<k} cdof_d * vec_d, k = 0 .. nv (6 floats each): a wave scan carried across the trips
   VNL_HD void dof_prefix(int vec, int Q) const {
     S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)}, carry = run;
-    VNL_FOR(d, VNL_PAD_ITEMS(m.nv)) {  // every lane takes part in the scans of every trip
+    VNL_FOR(d, VNL_PAD_ITEMS(MI(nv))) {  // every lane takes part in the scans of every trip
       S6 x = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      if (d < m.nv) x = ld6(L.cdof + 6 * d) * s[vec + d];
+      if (d < MI(nv)) x = ld6(LO(cdof) + 6 * d) * s[vec + d];
       VNL_SCAN_ADD_C(x.a.x, run.a.x, carry.a.x), VNL_SCAN_ADD_C(x.a.y, run.a.y, carry.a.y);
       VNL_SCAN_ADD_C(x.a.z, run.a.z, carry.a.z), VNL_SCAN_ADD_C(x.l.x, run.l.x, carry.l.x);
       VNL_SCAN_ADD_C(x.l.y, run.l.y, carry.l.y), VNL_SCAN_ADD_C(x.l.z, run.l.z, carry.l.z);
-      if (d < m.nv) st6(Q + 6 * (d + 1), x);
+      if (d < MI(nv)) st6(Q + 6 * (d + 1), x);
       if (d == 0) st6(Q, S6{v3(0, 0, 0), v3(0, 0, 0)});
     }
     VNL_SYNC();
@@ -1805,21 +1810,21 @@ struct EnvWave {
   VNL_HD void jac_mul(int vec, int out, bool accumulate) const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
     for_live_rows([&](int r) {
-      if (r < m.nlimit) {
-        vreal v = copysign(vreal(1.), s[L.efc_D + r]) * s[vec + m.lim_dof[r]];
+      if (r < MI(nlimit)) {
+        vreal v = copysign(vreal(1.), s[LO(efc_D) + r]) * s[vec + m.lim_dof[r]];
         s[out + r] = accumulate ? s[out + r] + v : v;
       }
     });
-    const int Q = L.P + 3 * m.nefc;  // the contact-wrench area of constraint_force: dead here
+    const int Q = LO(P) + 3 * MI(nefc);  // the contact-wrench area of constraint_force: dead here
     dof_prefix(vec, Q);
-    const unsigned char* act = (const unsigned char*)(s + L.act_list);
-    int na = ((const int*)(s + L.act_list))[(m.ncon + 3) / 4];
+    const unsigned char* act = (const unsigned char*)(s + LO(act_list));
+    int na = ((const int*)(s + LO(act_list)))[(MI(ncon) + 3) / 4];
     VNL_FOR(j, na) {
-      int c = act[j], g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
+      int c = act[j], g = m.con_geom[c] & 0xff, r0 = MI(nlimit) + 4 * c;
       const int* seg = m.body_pathseg + 8 * con_body(c);
       S6 vel = path_sum(Q, seg);
       vreal mu = m.cg_mu[g];
-      V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
+      V3 rel = ld3(LO(con_r) + 3 * c), t1 = ld3(LO(con_t1) + 3 * g), t2 = cross(n, t1);
       V3 pv = vel.l + cross(vel.a, rel);
       vreal jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
       vreal o0 = jn + j1, o1 = jn - j1, o2 = jn + j2, o3 = jn - j2;
@@ -1834,7 +1839,7 @@ struct EnvWave {
     vreal c = vreal(0.);
     for_live_rows([&](int r) {
       vreal x = s[jaref + r];
-      c += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
+      c += x < vreal(0.) ? fabs(s[LO(efc_D) + r]) * x * x : vreal(0.);
     });
     return vreal(0.5) * vnl_wave_sum(c);
   }
@@ -1846,12 +1851,12 @@ struct EnvWave {
   // built by make_constraint).
   VNL_HD vreal constraint_force() const {
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    int Wc = L.P + 3 * m.nefc;  // after efc_D | Jaref | jv
+    int Wc = LO(P) + 3 * MI(nefc);  // after efc_D | Jaref | jv
     vreal cost = vreal(0.);
     for_live_rows([&](int r) {
-      if (r < m.nlimit) {
-        vreal x = s[L.Jaref + r];
-        cost += x < vreal(0.) ? fabs(s[L.efc_D + r]) * x * x : vreal(0.);
+      if (r < MI(nlimit)) {
+        vreal x = s[LO(Jaref) + r];
+        cost += x < vreal(0.) ? fabs(s[LO(efc_D) + r]) * x * x : vreal(0.);
       }
     });
     {
@@ -1860,41 +1865,41 @@ struct EnvWave {
       // scan turns them into prefix sums P[k] = sum_{c<k}, and every dof takes P[c1] - P[c0] (exactly zero where
       // nothing is active) -- no loop over contacts per dof.
       S6 run = S6{v3(0, 0, 0), v3(0, 0, 0)};
-      VNL_FOR(k, VNL_WAVE_ITEMS(m.ncon)) {  // (ncon <= 64: one trip of ALL lanes; idle lanes carry zeros through the scan)
+      VNL_FOR(k, VNL_WAVE_ITEMS(MI(ncon))) {  // (ncon <= 64: one trip of ALL lanes; idle lanes carry zeros through the scan)
         S6 w = S6{v3(0, 0, 0), v3(0, 0, 0)};
-        if (k < m.ncon) {
+        if (k < MI(ncon)) {
           const int c = (m.con_geom[k] >> 8) & 0xff;  // the k-th contact in body order
-          int r0 = m.nlimit + 4 * c;
-          vreal D = s[L.efc_D + r0];
+          int r0 = MI(nlimit) + 4 * c;
+          vreal D = s[LO(efc_D) + r0];
           if (D != vreal(0.)) {
             int g = m.con_geom[c] & 0xff;
             vreal mu = m.cg_mu[g], f[4];
             for (int q = 0; q < 4; q++) {
-              vreal x = s[L.Jaref + r0 + q];
+              vreal x = s[LO(Jaref) + r0 + q];
               f[q] = x < vreal(0.) ? -D * x : vreal(0.);
               cost += x < vreal(0.) ? D * x * x : vreal(0.);
             }
-            V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
+            V3 rel = ld3(LO(con_r) + 3 * c), t1 = ld3(LO(con_t1) + 3 * g), t2 = cross(n, t1);
             V3 Fw = n * (f[0] + f[1] + f[2] + f[3]) + t1 * (mu * (f[0] - f[1])) + t2 * (mu * (f[2] - f[3]));
             w = S6{cross(rel, Fw), Fw};
           }
         }
         VNL_SCAN_ADD(w.a.x, run.a.x), VNL_SCAN_ADD(w.a.y, run.a.y), VNL_SCAN_ADD(w.a.z, run.a.z);
         VNL_SCAN_ADD(w.l.x, run.l.x), VNL_SCAN_ADD(w.l.y, run.l.y), VNL_SCAN_ADD(w.l.z, run.l.z);
-        if (k < m.ncon) st6(Wc + 6 * (k + 1), w);
+        if (k < MI(ncon)) st6(Wc + 6 * (k + 1), w);
         if (k == 0) st6(Wc, S6{v3(0, 0, 0), v3(0, 0, 0)});
       }
       VNL_SYNC();
-      VNL_FOR(d, m.nv) {
+      VNL_FOR(d, MI(nv)) {
         const int pk = m.dof_limrow[d], r = (pk & 0x3ff) - 1, c0 = (pk >> 10) & 0xff, c1 = (pk >> 18) & 0xff;
         S6 p1 = ld6(Wc + 6 * c1), p0 = ld6(Wc + 6 * c0);
         S6 w = S6{p1.a - p0.a, p1.l - p0.l};
-        vreal q = dot(ld6(L.cdof + 6 * d), w);
+        vreal q = dot(ld6(LO(cdof) + 6 * d), w);
         if (r >= 0) {
-          vreal x = s[L.Jaref + r];
-          q += x < vreal(0.) ? -s[L.efc_D + r] * x : vreal(0.);  // sign(D) is the limit Jacobian entry
+          vreal x = s[LO(Jaref) + r];
+          q += x < vreal(0.) ? -s[LO(efc_D) + r] * x : vreal(0.);  // sign(D) is the limit Jacobian entry
         }
-        s[L.qfrc_c + d] = q;
+        s[LO(qfrc_c) + d] = q;
       }
       VNL_SYNC();
       return vreal(0.5) * vnl_wave_sum(cost);
@@ -1904,7 +1909,7 @@ struct EnvWave {
 
   VNL_HD vreal vdot(int a, int b) const {
     vreal p = vreal(0.);
-    VNL_FOR(d, m.nv) p += s[a + d] * s[b + d];
+    VNL_FOR(d, MI(nv)) p += s[a + d] * s[b + d];
     return vnl_wave_sum(p);
   }
 
@@ -1925,7 +1930,7 @@ struct EnvWave {
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
-      bool live = r < m.nefc && s[L.efc_D + (r < m.nefc ? r : 0)] != vreal(0.);
+      bool live = r < MI(nefc) && s[LO(efc_D) + (r < MI(nefc) ? r : 0)] != vreal(0.);
       if (compact) live = (int)lane < num_live_rows();
       n += VNL_COUNT(live && R.ja[j] + alpha * R.jv[j] < vreal(0.));
     }
@@ -1936,13 +1941,13 @@ struct EnvWave {
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
-      bool ok = r < m.nefc;
+      bool ok = r < MI(nefc);
       if (compact) {  // (RPL == 1) lane l takes the l-th existing row
         ok = (int)lane < num_live_rows();
         r = ok ? (int)live_rows()[lane] : 0;
       }
-      vreal D = ok ? fabs(s[L.efc_D + r]) : vreal(0.);
-      vreal ja = ok ? s[L.Jaref + r] : vreal(0.), jv = ok ? s[L.jv + r] : vreal(0.);
+      vreal D = ok ? fabs(s[LO(efc_D) + r]) : vreal(0.);
+      vreal ja = ok ? s[LO(Jaref) + r] : vreal(0.), jv = ok ? s[LO(jv) + r] : vreal(0.);
       R.ja[j] = ja, R.jv[j] = jv;
       R.a0[j] = vreal(0.5) * ja * ja * D, R.a1[j] = jv * ja * D, R.a2[j] = vreal(0.5) * jv * jv * D;
     }
@@ -1996,7 +2001,7 @@ struct EnvWave {
         hi = lo, lo = p0;
       }
       bool swap = true;
-      for (int li = 0; li < m.ls_iterations; li++) {
+      for (int li = 0; li < MI(ls_iterations); li++) {
         if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
         vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
         LsPoint p[3];
@@ -2038,37 +2043,37 @@ struct EnvWave {
   // current active set, H = qM + J' diag(efc_D * active) J -- formed and Cholesky-factorised dense in LDS (small models: the
   // reference selects it for the ant, nv 14, configs/env_config.yaml:16-21).  efc_J is materialised once per substep.
   VNL_HD void newton_jacobian() const {
-    const int nv = m.nv;
+    const int nv = MI(nv);
     V3 n = v3(m.pnx, m.pny, m.pnz);
-    VNL_FOR(k, m.nefc * nv) s[L.newt_J + k] = vreal(0.);
+    VNL_FOR(k, MI(nefc) * nv) s[LO(newt_J) + k] = vreal(0.);
     VNL_SYNC();
-    VNL_FOR(r, m.nlimit) s[L.newt_J + r * nv + m.lim_dof[r]] = copysign(vreal(1.), s[L.efc_D + r]);
-    VNL_FOR(q, m.ncon * nv) {
-      const int c = q / nv, d = q - c * nv, g = m.con_geom[c] & 0xff, r0 = m.nlimit + 4 * c;
-      if (s[L.efc_D + r0] == vreal(0.)) continue;
+    VNL_FOR(r, MI(nlimit)) s[LO(newt_J) + r * nv + m.lim_dof[r]] = copysign(vreal(1.), s[LO(efc_D) + r]);
+    VNL_FOR(q, MI(ncon) * nv) {
+      const int c = q / nv, d = q - c * nv, g = m.con_geom[c] & 0xff, r0 = MI(nlimit) + 4 * c;
+      if (s[LO(efc_D) + r0] == vreal(0.)) continue;
       const int* seg = m.body_pathseg + 8 * con_body(c);
       bool on_path = false;
 #pragma unroll
       for (int k = 0; k < 4; k++) on_path = on_path || (d >= (seg[k] & 0xff) && d < (seg[k] >> 8));
       if (!on_path) continue;
-      const S6 cd = ld6(L.cdof + 6 * d);
-      const V3 rel = ld3(L.con_r + 3 * c), t1 = ld3(L.con_t1 + 3 * g), t2 = cross(n, t1);
+      const S6 cd = ld6(LO(cdof) + 6 * d);
+      const V3 rel = ld3(LO(con_r) + 3 * c), t1 = ld3(LO(con_t1) + 3 * g), t2 = cross(n, t1);
       const V3 pv = cd.l + cross(cd.a, rel);
       const vreal mu = m.cg_mu[g], jn = dot(n, pv), j1 = dot(t1, pv) * mu, j2 = dot(t2, pv) * mu;
-      s[L.newt_J + r0 * nv + d] = jn + j1, s[L.newt_J + (r0 + 1) * nv + d] = jn - j1;
-      s[L.newt_J + (r0 + 2) * nv + d] = jn + j2, s[L.newt_J + (r0 + 3) * nv + d] = jn - j2;
+      s[LO(newt_J) + r0 * nv + d] = jn + j1, s[LO(newt_J) + (r0 + 1) * nv + d] = jn - j1;
+      s[LO(newt_J) + (r0 + 2) * nv + d] = jn + j2, s[LO(newt_J) + (r0 + 3) * nv + d] = jn - j2;
     }
     VNL_SYNC();
   }
   // x <- H^-1 x (x: a dof vector in LDS); Jaref as it stands decides the active set
   VNL_HD void newton_solve(int x) const {
-    const int nv = m.nv, H = L.newt_H;
+    const int nv = MI(nv), H = LO(newt_H);
     VNL_FOR(k, nv * nv) {
       const int i = k / nv, j = k - i * nv;
-      vreal h = s[L.newt_M + k];
-      for (int r = 0; r < m.nefc; r++) {
-        const vreal D = s[L.efc_D + r];
-        if (D != vreal(0.) && s[L.Jaref + r] < vreal(0.)) h += fabs(D) * s[L.newt_J + r * nv + i] * s[L.newt_J + r * nv + j];
+      vreal h = s[LO(newt_M) + k];
+      for (int r = 0; r < MI(nefc); r++) {
+        const vreal D = s[LO(efc_D) + r];
+        if (D != vreal(0.) && s[LO(Jaref) + r] < vreal(0.)) h += fabs(D) * s[LO(newt_J) + r * nv + i] * s[LO(newt_J) + r * nv + j];
       }
       s[H + k] = h;
     }
@@ -2107,10 +2112,10 @@ struct EnvWave {
   }
   // out = qM v (dense copy): with search = -H^-1 grad the recurrence M s' = -grad + beta M s of the CG route does not hold
   VNL_HD void newton_mass_mul(int v, int out) const {
-    const int nv = m.nv;
+    const int nv = MI(nv);
     VNL_FOR(i, nv) {
       vreal acc = vreal(0.);
-      for (int j = 0; j < nv; j++) acc += s[L.newt_M + i * nv + j] * s[v + j];
+      for (int j = 0; j < nv; j++) acc += s[LO(newt_M) + i * nv + j] * s[v + j];
       s[out + i] = acc;
     }
     VNL_SYNC();
@@ -2118,29 +2123,29 @@ struct EnvWave {
 
   // solver.solve (CG / Newton).  One env per wave: the while loops run with this env's own trip counts.
   VNL_HD void solve() const {
-    const int nv = m.nv, ne = m.nefc;
+    const int nv = MI(nv), ne = MI(nefc);
     // --- warm start selection: cost at qacc_warmstart vs qacc_smooth.
     // On entry: Jaref holds -aref (make_constraint), mv holds M*warm, qacc holds warm (forward()).
-    fresh().jac_mul(L.qacc_smooth, L.Jaref, true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
-    vreal cost_s = fresh().constraint_cost(L.Jaref);  // gauss term vanishes: M qacc_smooth = qfrc_smooth
-    VNL_FOR(d, nv) s[L.tmp + d] = s[L.qacc + d] - s[L.qacc_smooth + d];
+    fresh().jac_mul(LO(qacc_smooth), LO(Jaref), true);  // Jaref(qacc_smooth) = J qacc_smooth - aref
+    vreal cost_s = fresh().constraint_cost(LO(Jaref));  // gauss term vanishes: M qacc_smooth = qfrc_smooth
+    VNL_FOR(d, nv) s[LO(tmp) + d] = s[LO(qacc) + d] - s[LO(qacc_smooth) + d];
     VNL_SYNC();
-    fresh().jac_mul(L.tmp, L.jv, false);  // J (warm - smooth)
-    for_live_rows([&](int r) { s[L.jv + r] += s[L.Jaref + r]; });  // Jaref(warm)
+    fresh().jac_mul(LO(tmp), LO(jv), false);  // J (warm - smooth)
+    for_live_rows([&](int r) { s[LO(jv) + r] += s[LO(Jaref) + r]; });  // Jaref(warm)
     vreal gw = vreal(0.);
-    VNL_FOR(d, nv) gw += (s[L.mv + d] - s[L.smooth + d]) * s[L.tmp + d];
+    VNL_FOR(d, nv) gw += (s[LO(mv) + d] - s[LO(smooth) + d]) * s[LO(tmp) + d];
     gw = vnl_wave_sum(gw);
     VNL_SYNC();
-    vreal cost_w = fresh().constraint_cost(L.jv) + vreal(0.5) * gw;
+    vreal cost_w = fresh().constraint_cost(LO(jv)) + vreal(0.5) * gw;
     bool use_warm = cost_w < cost_s;
     if (trace) {
       VNL_FOR(k, VNL_TRACE_ROWS) trace[k] = k == 0 ? (int)use_warm : 0;
     }
     VNL_FOR(d, nv) {
-      s[L.qacc + d] = use_warm ? s[L.qacc + d] : s[L.qacc_smooth + d];
-      s[L.Ma + d] = use_warm ? s[L.mv + d] : s[L.smooth + d];
+      s[LO(qacc) + d] = use_warm ? s[LO(qacc) + d] : s[LO(qacc_smooth) + d];
+      s[LO(Ma) + d] = use_warm ? s[LO(mv) + d] : s[LO(smooth) + d];
     }
-    if (use_warm) for_live_rows([&](int r) { s[L.Jaref + r] = s[L.jv + r]; });
+    if (use_warm) for_live_rows([&](int r) { s[LO(Jaref) + r] = s[LO(jv) + r]; });
     VNL_SYNC();
     VNL_PROF(14);
     vreal gauss = use_warm ? vreal(0.5) * gw : vreal(0.);
@@ -2151,31 +2156,31 @@ struct EnvWave {
     // of their own at the top of every iteration.
     vreal gg = vreal(0.), ss = vreal(0.), gp = vreal(0.);
     VNL_FOR(d, nv) {
-      vreal g = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
-      s[L.grad + d] = g, s[L.Mgrad + d] = g;
+      vreal g = s[LO(Ma) + d] - s[LO(smooth) + d] - s[LO(qfrc_c) + d];
+      s[LO(grad) + d] = g, s[LO(Mgrad) + d] = g;
       gg += g * g;
     }
     gg = vnl_wave_sum(gg);
     VNL_SYNC();
-    const bool newton = m.solver_newton != 0;
+    const bool newton = MI(solver_newton) != 0;
     if (newton) {
       fresh().newton_jacobian();
-      fresh().newton_solve(L.Mgrad);
+      fresh().newton_solve(LO(Mgrad));
     } else {
-      fresh().solve_inplace(L.Mgrad);
+      fresh().solve_inplace(LO(Mgrad));
     }
     VNL_FOR(d, nv) {
-      const vreal mg = s[L.Mgrad + d], gr = s[L.grad + d];
-      s[L.search + d] = -mg;
-      s[L.mv + d] = -gr;  // M search (CG: search = -M^-1 grad)
+      const vreal mg = s[LO(Mgrad) + d], gr = s[LO(grad) + d];
+      s[LO(search) + d] = -mg;
+      s[LO(mv) + d] = -gr;  // M search (CG: search = -M^-1 grad)
       ss += mg * mg, gp += gr * mg;
     }
     ss = vnl_wave_sum(ss), gp = vnl_wave_sum(gp);
     VNL_SYNC();
-    if (newton) fresh().newton_mass_mul(L.search, L.mv);
+    if (newton) fresh().newton_mass_mul(LO(search), LO(mv));
     VNL_PROF(15);
 
-    for (int it = 0; it < m.iterations; it++) {
+    for (int it = 0; it < MI(iterations); it++) {
       vreal improvement = (prev_cost - cost) / m.scale;
       vreal gradient = sqrt(gg) / m.scale;
       if (improvement < m.tolerance || gradient < m.tolerance) break;
@@ -2183,13 +2188,13 @@ struct EnvWave {
       vreal smag = sqrt(ss) * m.scale;
       vreal gtol = m.tolerance * m.ls_tolerance * smag;
       VNL_PROF(16);
-      fresh().jac_mul(L.search, L.jv, false);
+      fresh().jac_mul(LO(search), LO(jv), false);
       VNL_PROF(17);
       vreal qg1 = vreal(0.), qg2 = vreal(0.);
       VNL_FOR(d, nv) {
-        vreal sd = s[L.search + d];
-        qg1 += sd * s[L.Ma + d] - sd * s[L.smooth + d];
-        qg2 += sd * s[L.mv + d];
+        vreal sd = s[LO(search) + d];
+        qg1 += sd * s[LO(Ma) + d] - sd * s[LO(smooth) + d];
+        qg2 += sd * s[LO(mv) + d];
       }
       qg1 = vnl_wave_sum(qg1), qg2 = vreal(0.5) * vnl_wave_sum(qg2);
       VNL_PROF(18);
@@ -2200,19 +2205,19 @@ struct EnvWave {
       }
       vreal alpha = (num_live_rows() <= (VNL_LANES < VNL_LIVE_MAX ? VNL_LANES : VNL_LIVE_MAX))
                         ? fresh().template line_search<1, true>(gauss, qg1, qg2, gtol, tr)
-                        : ((m.nefc <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
+                        : ((MI(nefc) <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
                                                      : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol, tr));
       VNL_FOR(d, nv) {
-        s[L.qacc + d] += alpha * s[L.search + d];
-        s[L.Ma + d] += alpha * s[L.mv + d];
+        s[LO(qacc) + d] += alpha * s[LO(search) + d];
+        s[LO(Ma) + d] += alpha * s[LO(mv) + d];
       }
       VNL_PROF(19);
-      for_live_rows([&](int r) { s[L.Jaref + r] += alpha * s[L.jv + r]; });
+      for_live_rows([&](int r) { s[LO(Jaref) + r] += alpha * s[LO(jv) + r]; });
       VNL_SYNC();
       VNL_PROF(20);
       // ---- constraint + gradient update   (gp = grad . Mgrad of the vectors as they stand: carried, see above)
       vreal g = vreal(0.);
-      VNL_FOR(d, nv) g += (s[L.Ma + d] - s[L.smooth + d]) * (s[L.qacc + d] - s[L.qacc_smooth + d]);
+      VNL_FOR(d, nv) g += (s[LO(Ma) + d] - s[LO(smooth) + d]) * (s[LO(qacc) + d] - s[LO(qacc_smooth) + d]);
       g = vnl_wave_sum(g);
       VNL_PROF(21);
       vreal ncost = fresh().constraint_force() + vreal(0.5) * g;
@@ -2221,42 +2226,42 @@ struct EnvWave {
       vreal d1 = vreal(0.);
       gg = vreal(0.);
       VNL_FOR(d, nv) {
-        vreal gn = s[L.Ma + d] - s[L.smooth + d] - s[L.qfrc_c + d];
-        d1 += gn * s[L.Mgrad + d];
-        s[L.grad + d] = gn, s[L.tmp + d] = gn;
+        vreal gn = s[LO(Ma) + d] - s[LO(smooth) + d] - s[LO(qfrc_c) + d];
+        d1 += gn * s[LO(Mgrad) + d];
+        s[LO(grad) + d] = gn, s[LO(tmp) + d] = gn;
         gg += gn * gn;
       }
       d1 = vnl_wave_sum(d1), gg = vnl_wave_sum(gg);
       VNL_SYNC();
       VNL_PROF(23);
-      if (newton) fresh().newton_solve(L.tmp);
-      else fresh().solve_inplace(L.tmp);
+      if (newton) fresh().newton_solve(LO(tmp));
+      else fresh().solve_inplace(LO(tmp));
       VNL_PROF(24);
-      vreal d2 = vdot(L.grad, L.tmp);
+      vreal d2 = vdot(LO(grad), LO(tmp));
       vreal beta = fmax(vreal(0.), (d2 - d1) / fmax(VNL_MINVAL, gp));
       if (newton) beta = vreal(0.);  // solver.solve: search = -Mgrad
       gp = d2;  // grad . Mgrad with Mgrad := tmp below
       ss = vreal(0.);
       VNL_FOR(d, nv) {
-        vreal mg = s[L.tmp + d];
-        s[L.Mgrad + d] = mg;
-        const vreal sn = -mg + beta * s[L.search + d];
-        s[L.search + d] = sn;
-        s[L.mv + d] = -s[L.grad + d] + beta * s[L.mv + d];
+        vreal mg = s[LO(tmp) + d];
+        s[LO(Mgrad) + d] = mg;
+        const vreal sn = -mg + beta * s[LO(search) + d];
+        s[LO(search) + d] = sn;
+        s[LO(mv) + d] = -s[LO(grad) + d] + beta * s[LO(mv) + d];
         ss += sn * sn;
       }
       ss = vnl_wave_sum(ss);
       VNL_SYNC();
-      if (newton) fresh().newton_mass_mul(L.search, L.mv);
+      if (newton) fresh().newton_mass_mul(LO(search), LO(mv));
       VNL_PROF(25);
     }
   }
 
   // forward.forward.  `warm` = qacc_warmstart (HBM on the first substep, LDS qacc afterwards).
   VNL_HD void forward(const vreal* warm) const {
-    VNL_FOR(d, m.nv) s[L.tmp + d] = warm[d];
+    VNL_FOR(d, MI(nv)) s[LO(tmp) + d] = warm[d];
     VNL_SYNC();
-    VNL_FOR(d, m.nv) s[L.qacc + d] = s[L.tmp + d];
+    VNL_FOR(d, MI(nv)) s[LO(qacc) + d] = s[LO(tmp) + d];
     VNL_SYNC();
     // Timing knob (VNL_DBG_REPEAT=stage:count at env creation; 0 in normal use): run one stage
     // `count` extra times on data that is recomputed afterwards, so results are unchanged and the
@@ -2304,11 +2309,11 @@ struct EnvWave {
         }
       } else if (m.dbg_stage == 16) {  // euler()'s second-factor route: reload, apply
         const vreal* g2 = fac2();
-        VNL_FOR(k, m.nM + m.nv) s[L.P + k] = g2[k];
+        VNL_FOR(k, MI(nM) + MI(nv)) s[LO(P) + k] = g2[k];
         VNL_SYNC();
-        solve_inplace(L.tmp, L.P, L.P + m.nM);
+        solve_inplace(LO(tmp), LO(P), LO(P) + MI(nM));
       } else if (m.dbg_stage == 18) {
-        tree_accumulate(L.P, 10);
+        tree_accumulate(LO(P), 10);
       } else if (m.dbg_stage == 19) {
         body_inertias(false);
       }
@@ -2322,12 +2327,12 @@ struct EnvWave {
     fresh().mass_matrix(vreal(0.));
     if (factor_pair_ok()) {
       fresh().factor_both(m.dt);
-      fresh().mass_mul_pair(L.qacc, L.mv, pair_base(), pair_dinv());  // M * qacc_warmstart, needs L (before it becomes L^-1)
+      fresh().mass_mul_pair(LO(qacc), LO(mv), pair_base(), pair_dinv());  // M * qacc_warmstart, needs L (before it becomes L^-1)
       VNL_PROF(10);
       fresh().invert_both(pair_base(), pair_dinv(), fac2());
     } else {
       fresh().factor();
-      fresh().mass_mul_factor(L.qacc, L.mv);
+      fresh().mass_mul_factor(LO(qacc), LO(mv));
       VNL_PROF(10);
       fresh().invert_factor();
     }
@@ -2339,88 +2344,88 @@ struct EnvWave {
 #ifdef VNL_STAGE_KNOBS
     for (int rep = 0; rep < m.dbg_count; rep++) {
       if (m.dbg_stage == 6) {
-        jac_mul(L.qacc_smooth, L.jv, false);
+        jac_mul(LO(qacc_smooth), LO(jv), false);
       } else if (m.dbg_stage == 7) {
-        VNL_FOR(d, m.nv) s[L.tmp + d] = s[L.smooth + d];
+        VNL_FOR(d, MI(nv)) s[LO(tmp) + d] = s[LO(smooth) + d];
         VNL_SYNC();
-        solve_inplace(L.tmp);
+        solve_inplace(LO(tmp));
       } else if (m.dbg_stage == 8) {
         vreal a3[3] = {vreal(0.), vreal(1e-4), vreal(2e-4)};
         LsPoint p[3];
         LsRows<VNL_ROWS_SMALL> rows;
         ls_load(rows, false);
         ls_eval<3>(rows, a3, vreal(0.), vreal(0.), vreal(0.), p);
-        if (p[0].cost == vreal(-1.)) s[L.tmp] = p[1].cost;  // keep the result alive
+        if (p[0].cost == vreal(-1.)) s[LO(tmp)] = p[1].cost;  // keep the result alive
       } else if (m.dbg_stage == 9) {
         make_constraint(cvel);
       } else if (m.dbg_stage == 10) {
         vreal c = constraint_force();
-        if (c == vreal(-1.)) s[L.tmp] = c;
+        if (c == vreal(-1.)) s[LO(tmp)] = c;
       } else if (m.dbg_stage == 11) {
         smooth_forces();
       } else if (m.dbg_stage == 12) {
-        vreal c = vdot(L.smooth, L.qacc_smooth) + vdot(L.qacc, L.smooth) + vdot(L.qacc, L.qacc) + vdot(L.smooth, L.smooth);
-        if (c == vreal(-1.)) s[L.tmp] = c;
+        vreal c = vdot(LO(smooth), LO(qacc_smooth)) + vdot(LO(qacc), LO(smooth)) + vdot(LO(qacc), LO(qacc)) + vdot(LO(smooth), LO(smooth));
+        if (c == vreal(-1.)) s[LO(tmp)] = c;
       } else if (m.dbg_stage == 13) {
         LsRows<VNL_ROWS_SMALL> rows;
         ls_load(rows, false);
         vreal a1[1] = {vreal(1e-4)};
         LsPoint p;
         ls_eval<1>(rows, a1, vreal(0.), vreal(0.), vreal(0.), &p);
-        if (p.cost == vreal(-1.)) s[L.tmp] = p.cost;
+        if (p.cost == vreal(-1.)) s[LO(tmp)] = p.cost;
       }
     }
 #endif
     fresh().solve();
   }
 
-  // forward.euler + _advance; leaves qacc (warm start) in L.qacc and the new state in L.qpos/qvel/act
+  // forward.euler + _advance; leaves qacc (warm start) in LO(qacc) and the new state in LO(qpos)/qvel/act
   VNL_HD void euler() const {
-    const int nv = m.nv;
+    const int nv = MI(nv);
     VNL_PROF(26);  // the tail of solve()
-    VNL_FOR(d, nv) s[L.tmp + d] = m.eulerdamp ? s[L.smooth + d] + s[L.qfrc_c + d] : s[L.qacc + d];
+    VNL_FOR(d, nv) s[LO(tmp) + d] = MI(eulerdamp) ? s[LO(smooth) + d] + s[LO(qfrc_c) + d] : s[LO(qacc) + d];
     VNL_SYNC();
-    if (m.eulerdamp && factor_pair_ok()) {
+    if (MI(eulerdamp) && factor_pair_ok()) {
       // the INVERTED factor of M + h diag(damping) was made beside M's by forward() (factor_pair + invert_pair): bring it
       // into the pool (the constraint rows are dead now) and apply it
       const vreal* g2 = fac2();
-      const int n2 = m.nM + m.nv;
+      const int n2 = MI(nM) + MI(nv);
       VNL_SYNC_GLOBAL();  // (written by invert_pair, one row per lane; read here element by element)
-      VNL_FOR(k, n2) s[L.P + k] = g2[k];
+      VNL_FOR(k, n2) s[LO(P) + k] = g2[k];
       VNL_SYNC();
-      fresh().solve_inplace(L.tmp, L.P, L.P + m.nM);
+      fresh().solve_inplace(LO(tmp), LO(P), LO(P) + MI(nM));
       VNL_PROF(27);
-    } else if (m.eulerdamp) {
+    } else if (MI(eulerdamp)) {
       fresh().body_inertias(false);
       VNL_PROF(1);
       fresh().mass_matrix(m.dt);
-      if (!fresh().factor_solve(L.tmp)) {
+      if (!fresh().factor_solve(LO(tmp))) {
         fresh().factor();
         fresh().invert_factor();
-        fresh().solve_inplace(L.tmp);
+        fresh().solve_inplace(LO(tmp));
       }
       VNL_PROF(27);
     }
-    VNL_FOR(i, m.nu) {
-      if (m.act_tau[i] >= vreal(0.)) s[L.act + i] += s[L.actdot + i] * m.dt;
+    VNL_FOR(i, MI(nu)) {
+      if (m.act_tau[i] >= vreal(0.)) s[LO(act) + i] += s[LO(actdot) + i] * m.dt;
     }
-    VNL_FOR(d, nv) s[L.qvel + d] += s[L.tmp + d] * m.dt;
+    VNL_FOR(d, nv) s[LO(qvel) + d] += s[LO(tmp) + d] * m.dt;
     VNL_SYNC();
-    VNL_FOR(j, m.njnt) {
+    VNL_FOR(j, MI(njnt)) {
       int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
       if (m.jnt_type[j] == VNL_JNT_FREE) {
-        for (int t = 0; t < 3; t++) s[L.qpos + qa + t] += m.dt * s[L.qvel + da + t];
-        V3 w = ld3(L.qvel + da + 3);
+        for (int t = 0; t < 3; t++) s[LO(qpos) + qa + t] += m.dt * s[LO(qvel) + da + t];
+        V3 w = ld3(LO(qvel) + da + 3);
         vreal nrm = sqrt(dot(w, w));
         V3 ax = nrm > vreal(0.) ? w * (vreal(1.) / nrm) : w;
         vreal ang = m.dt * nrm, sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
-        Q4 r = qmul(ld4(L.qpos + qa + 3), Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
+        Q4 r = qmul(ld4(LO(qpos) + qa + 3), Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
         vreal n2 = sqrt(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
         vreal inv = n2 > vreal(0.) ? vreal(1.) / n2 : vreal(1.);
-        s[L.qpos + qa + 3] = r.w * inv, s[L.qpos + qa + 4] = r.x * inv, s[L.qpos + qa + 5] = r.y * inv,
-                        s[L.qpos + qa + 6] = r.z * inv;
+        s[LO(qpos) + qa + 3] = r.w * inv, s[LO(qpos) + qa + 4] = r.x * inv, s[LO(qpos) + qa + 5] = r.y * inv,
+                        s[LO(qpos) + qa + 6] = r.z * inv;
       } else {
-        s[L.qpos + qa] += m.dt * s[L.qvel + da];
+        s[LO(qpos) + qa] += m.dt * s[LO(qvel) + da];
       }
     }
     VNL_SYNC();
@@ -2440,7 +2445,7 @@ struct EnvWave {
   // rodent.py:241-264 (matrix 1-norm over the tracked bodies, L1 over joints); qpos / xpos given
   // as pointers so that both the carried (global) and the fresh (LDS) state can be scored
   VNL_HD vreal termination(int clip, int frame, const vreal* qpos, const vreal* xpos) const {
-    int f = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
+    int f = clampi(frame, 0, ev.T - 1), nj = MI(nq) - 7;
     const float* cj = ev.joints + ((size_t)clip * ev.T + f) * nj;
     const float* cb = ev.body_positions + ((size_t)clip * ev.T + f) * ev.nb * 3;
     vreal ej = vreal(0.), cx = vreal(0.), cy = vreal(0.), cz = vreal(0.);
@@ -2463,43 +2468,43 @@ struct EnvWave {
 
   // carried state: HBM -> LDS
   VNL_HD void load_state() const {
-    const vreal* gq = st.qpos + (size_t)e * m.nq;
-    const vreal* gv = st.qvel + (size_t)e * m.nv;
-    const vreal* ga = st.act + (size_t)e * m.nu;
-    VNL_FOR(i, m.nq) s[L.qpos + i] = gq[i];
-    VNL_FOR(i, m.nv) s[L.qvel + i] = gv[i];
-    VNL_FOR(i, m.nu) s[L.act + i] = ga[i];
+    const vreal* gq = st.qpos + (size_t)e * MI(nq);
+    const vreal* gv = st.qvel + (size_t)e * MI(nv);
+    const vreal* ga = st.act + (size_t)e * MI(nu);
+    VNL_FOR(i, MI(nq)) s[LO(qpos) + i] = gq[i];
+    VNL_FOR(i, MI(nv)) s[LO(qvel) + i] = gv[i];
+    VNL_FOR(i, MI(nu)) s[LO(act) + i] = ga[i];
     VNL_SYNC();
   }
 
   // new state + derived quantities: LDS -> HBM; returns true if anything is NaN
   VNL_HD bool store_state() const {
-    vreal* gq = st.qpos + (size_t)e * m.nq;
-    vreal* gv = st.qvel + (size_t)e * m.nv;
-    vreal* ga = st.act + (size_t)e * m.nu;
-    vreal* gw = st.warm + (size_t)e * m.nv;
+    vreal* gq = st.qpos + (size_t)e * MI(nq);
+    vreal* gv = st.qvel + (size_t)e * MI(nv);
+    vreal* ga = st.act + (size_t)e * MI(nu);
+    vreal* gw = st.warm + (size_t)e * MI(nv);
     const vreal* gf = gqfrc_act();
     const vreal* gx = gxpos();
     bool bad = false;
-    VNL_FOR(i, m.nq) {
-      vreal v = s[L.qpos + i];
+    VNL_FOR(i, MI(nq)) {
+      vreal v = s[LO(qpos) + i];
       gq[i] = v, bad |= v != v;
     }
-    VNL_FOR(i, m.nv) {
-      vreal a = s[L.qvel + i], b = s[L.qacc + i], c = gf[i];
+    VNL_FOR(i, MI(nv)) {
+      vreal a = s[LO(qvel) + i], b = s[LO(qacc) + i], c = gf[i];
       gv[i] = a, gw[i] = b;
       bad |= (a != a) | (b != b) | (c != c);
     }
-    VNL_FOR(i, m.nu) {
-      vreal v = s[L.act + i];
+    VNL_FOR(i, MI(nu)) {
+      vreal v = s[LO(act) + i];
       ga[i] = v, bad |= v != v;
     }
-    VNL_FOR(i, 3 * m.nbody) {
+    VNL_FOR(i, 3 * MI(nbody)) {
       vreal v = gx[i];
       bad |= v != v;
     }
     VNL_FOR(i, 3) {
-      vreal v = s[L.com + i];
+      vreal v = s[LO(com) + i];
       st.com1[(size_t)e * 3 + i] = v, bad |= v != v;
     }
     return vnl_wave_any(bad);
@@ -2508,18 +2513,18 @@ struct EnvWave {
   // rodent.py:318-344
   VNL_HD void write_obs() const {
     vreal* o = st.obs + (size_t)e * ev.obs_size;
-    VNL_FOR(i, m.nq) o[i] = nan0(s[L.qpos + i]);
-    VNL_FOR(i, m.nv) o[m.nq + i] = nan0(s[L.qvel + i]);
+    VNL_FOR(i, MI(nq)) o[i] = nan0(s[LO(qpos) + i]);
+    VNL_FOR(i, MI(nv)) o[MI(nq) + i] = nan0(s[LO(qvel) + i]);
     if (ev.flags & VNL_ENV_OBS_QPOS_QVEL) return;  // humanoid.py:354-368
     const vreal* gf = gqfrc_act();
     const vreal* gx = gxpos();
-    VNL_FOR(i, m.nv) o[m.nq + m.nv + i] = nan0(gf[i]);
-    VNL_FOR(k, 3 * ev.nee) o[m.nq + 2 * m.nv + k] = nan0(gx[3 * ev.end_eff_idx[k / 3] + k % 3]);
+    VNL_FOR(i, MI(nv)) o[MI(nq) + MI(nv) + i] = nan0(gf[i]);
+    VNL_FOR(k, 3 * ev.nee) o[MI(nq) + 2 * MI(nv) + k] = nan0(gx[3 * ev.end_eff_idx[k / 3] + k % 3]);
   }
 
   // rodent.py:346-448; local frame = v @ xmat[1]
   VNL_HD void write_traj(int clip, int frame) const {
-    int Lr = ev.ref_len, s0 = clampi(frame + 1, 0, ev.T - Lr), nj = m.nq - 7;
+    int Lr = ev.ref_len, s0 = clampi(frame + 1, 0, ev.T - Lr), nj = MI(nq) - 7;
     M3 R = qmat(gquat4(1));
     const vreal* gx = gxpos();
     size_t fb = (size_t)clip * ev.T + s0;
@@ -2542,7 +2547,7 @@ struct EnvWave {
     }
     VNL_FOR(t, Lr) {  // root, local
       const float* cp = ev.position + (fb + t) * 3;
-      V3 v = V3{vreal(cp[0]) - s[L.qpos], vreal(cp[1]) - s[L.qpos + 1], vreal(cp[2]) - s[L.qpos + 2]};
+      V3 v = V3{vreal(cp[0]) - s[LO(qpos)], vreal(cp[1]) - s[LO(qpos) + 1], vreal(cp[2]) - s[LO(qpos) + 2]};
       vreal* o = tr + n_app + 2 * n_bod + 3 * t;
       o[0] = v.x * R.a[0] + v.y * R.a[3] + v.z * R.a[6];
       o[1] = v.x * R.a[1] + v.y * R.a[4] + v.z * R.a[7];
@@ -2550,7 +2555,7 @@ struct EnvWave {
     }
     VNL_FOR(k, n_j) {  // joints
       int t = k / ev.njc, col = ev.joint_cols[k % ev.njc];
-      tr[n_app + 2 * n_bod + n_root + k] = vreal(ev.joints[(fb + t) * nj + col]) - s[L.qpos + 7 + col];
+      tr[n_app + 2 * n_bod + n_root + k] = vreal(ev.joints[(fb + t) * nj + col]) - s[LO(qpos) + 7 + col];
     }
   }
 
@@ -2563,37 +2568,37 @@ struct EnvWave {
   // frames of a clip): xpos / xquat / subtree_com1 of the state buffers are the outputs.
   VNL_HD void fk(const vreal* qpos_in) const {
     load_tables();
-    const vreal* q = qpos_in + (size_t)e * m.nq;
-    VNL_FOR(k, m.nq) s[L.qpos + k] = q[k];
-    VNL_FOR(d, m.nv) s[L.qvel + d] = vreal(0.);
+    const vreal* q = qpos_in + (size_t)e * MI(nq);
+    VNL_FOR(k, MI(nq)) s[LO(qpos) + k] = q[k];
+    VNL_FOR(d, MI(nv)) s[LO(qvel) + d] = vreal(0.);
     VNL_SYNC();
     fresh().kinematics();
     fresh().body_inertias(true);
-    VNL_FOR(i, 3) st.com1[(size_t)e * 3 + i] = s[L.com + i];
-    VNL_FOR(k, 4) st.qpos[(size_t)e * m.nq + 3 + k] = s[L.qpos + 3 + k];  // the root quaternion as kinematics normalised it
+    VNL_FOR(i, 3) st.com1[(size_t)e * 3 + i] = s[LO(com) + i];
+    VNL_FOR(k, 4) st.qpos[(size_t)e * MI(nq) + 3 + k] = s[LO(qpos) + 3 + k];  // the root quaternion as kinematics normalised it
   }
 
   VNL_HD void reset(const int* start_frame, const vreal* noise, int* trace_base) const {
     load_tables();
     int clip = st.clip_id[e], sf = start_frame[e];
-    int f = clampi(sf, 0, ev.T - 1), nj = m.nq - 7;
+    int f = clampi(sf, 0, ev.T - 1), nj = MI(nq) - 7;
     size_t fb = (size_t)clip * ev.T + f;
-    const vreal* nz = noise + (size_t)e * m.nq;
-    VNL_FOR(k, 3) s[L.qpos + k] = vreal(ev.position[fb * 3 + k]) + nz[k];
-    VNL_FOR(k, 4) s[L.qpos + 3 + k] = vreal(ev.quaternion[fb * 4 + k]) + nz[3 + k];
-    VNL_FOR(k, nj) s[L.qpos + 7 + k] = vreal(ev.joints[fb * nj + k]) + nz[7 + k];
-    VNL_FOR(k, 3) s[L.qvel + k] = ev.velocity[fb * 3 + k];
-    VNL_FOR(k, 3) s[L.qvel + 3 + k] = ev.angular_velocity[fb * 3 + k];
-    VNL_FOR(k, nj) s[L.qvel + 6 + k] = ev.joints_velocity[fb * nj + k];
-    VNL_FOR(i, m.nu) s[L.act + i] = vreal(0.), s[L.ctrl + i] = vreal(0.);
-    VNL_FOR(d, m.nv) s[L.qacc + d] = vreal(0.);
+    const vreal* nz = noise + (size_t)e * MI(nq);
+    VNL_FOR(k, 3) s[LO(qpos) + k] = vreal(ev.position[fb * 3 + k]) + nz[k];
+    VNL_FOR(k, 4) s[LO(qpos) + 3 + k] = vreal(ev.quaternion[fb * 4 + k]) + nz[3 + k];
+    VNL_FOR(k, nj) s[LO(qpos) + 7 + k] = vreal(ev.joints[fb * nj + k]) + nz[7 + k];
+    VNL_FOR(k, 3) s[LO(qvel) + k] = ev.velocity[fb * 3 + k];
+    VNL_FOR(k, 3) s[LO(qvel) + 3 + k] = ev.angular_velocity[fb * 3 + k];
+    VNL_FOR(k, nj) s[LO(qvel) + 6 + k] = ev.joints_velocity[fb * nj + k];
+    VNL_FOR(i, MI(nu)) s[LO(act) + i] = vreal(0.), s[LO(ctrl) + i] = vreal(0.);
+    VNL_FOR(d, MI(nv)) s[LO(qacc) + d] = vreal(0.);
     VNL_SYNC();
-    with_trace(trace_of(trace_base, 0)).forward(s + L.qacc);  // qacc_warmstart = 0 (mjx.make_data)
+    with_trace(trace_of(trace_base, 0)).forward(s + LO(qacc));  // qacc_warmstart = 0 (mjx.make_data)
     VNL_SYNC_GLOBAL();
     store_state();
     write_traj(clip, sf);
     write_obs();
-    vreal term = termination(clip, sf, s + L.qpos, gxpos());
+    vreal term = termination(clip, sf, s + LO(qpos), gxpos());
     VNL_SERIAL {
       st.reward[e] = vreal(0.), st.done[e] = vreal(0.);
       for (int k = 0; k < 7; k++) st.metrics[(size_t)e * 7 + k] = vreal(0.);
@@ -2609,7 +2614,7 @@ struct EnvWave {
   };
   VNL_HD RewardTerms reward_terms(int clip, int frame, const vreal* qpos, const vreal* qvel, const vreal* com, const vreal* qfrc,
                                   const vreal* xpos, const vreal* action) const {
-    int fo = clampi(frame, 0, ev.T - 1), nj = m.nq - 7;
+    int fo = clampi(frame, 0, ev.T - 1), nj = MI(nq) - 7;
     size_t fb = (size_t)clip * ev.T + fo;
     const float* cb = ev.body_positions + fb * ev.nb * 3;
     const float* cref = ev.center_of_mass ? ev.center_of_mass + fb * 3 : cb + 3 * ev.com_ref_col;
@@ -2617,7 +2622,7 @@ struct EnvWave {
     RewardTerms r;
     r.rcom = exp(vreal(-100.) * sqrt(dot(dc, dc)));
     vreal acc = vreal(0.);
-    VNL_FOR(k, m.nv) {
+    VNL_FOR(k, MI(nv)) {
       vreal ref = k < 3 ? ev.velocity[fb * 3 + k] : (k < 6 ? ev.angular_velocity[fb * 3 + k - 3] : ev.joints_velocity[fb * nj + k - 6]);
       vreal a = qvel[k] - ref;
       acc += a * a;
@@ -2633,11 +2638,11 @@ struct EnvWave {
     r.rquat = exp(vreal(-2.) * fabs(vreal(0.5) * acos(dist)));
     acc = vreal(0.);
     if (ev.flags & VNL_ENV_RACT_ACTION) {  // ant.py:277: 0.01 * -0.015 * sum(action^2) / len(action)
-      VNL_FOR(i, m.nu) acc += action[i] * action[i];
-      r.ract = vreal(0.01) * vreal(-0.015) * vnl_wave_sum(acc) / (vreal)m.nu;
+      VNL_FOR(i, MI(nu)) acc += action[i] * action[i];
+      r.ract = vreal(0.01) * vreal(-0.015) * vnl_wave_sum(acc) / (vreal)MI(nu);
     } else {
-      VNL_FOR(d, m.nv) acc += qfrc[d] * qfrc[d];
-      r.ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)m.nv);
+      VNL_FOR(d, MI(nv)) acc += qfrc[d] * qfrc[d];
+      r.ract = vreal(-0.015) * (vnl_wave_sum(acc) / (vreal)MI(nv));
     }
     r.rapp = vreal(0.);
     if (!(ev.flags & VNL_ENV_NO_RAPP)) {
@@ -2662,20 +2667,20 @@ struct EnvWave {
     load_tables();
     load_state();
     // rtrunk from the OLD pipeline state and OLD frame (rodent.py:250-262, 296)
-    vreal rtrunk = termination(clip, old_frame, s + L.qpos, st.xpos + (size_t)e * 3 * m.nbody);
-    const vreal* ac = action + (size_t)e * m.nu;
-    VNL_FOR(i, m.nu) {
+    vreal rtrunk = termination(clip, old_frame, s + LO(qpos), st.xpos + (size_t)e * 3 * MI(nbody));
+    const vreal* ac = action + (size_t)e * MI(nu);
+    VNL_FOR(i, MI(nu)) {
       vreal c = ac[i];
       // jnp.clip semantics: a NaN control stays NaN (and ends the episode below); fmin / fmax would swallow it
       if (m.act_limited[i]) c = c < m.act_lo[i] ? m.act_lo[i] : (c > m.act_hi[i] ? m.act_hi[i] : c);
-      s[L.ctrl + i] = c;
+      s[LO(ctrl) + i] = c;
     }
     VNL_SYNC();
-    const vreal* gw = st.warm + (size_t)e * m.nv;
+    const vreal* gw = st.warm + (size_t)e * MI(nv);
     if (ev.flags & VNL_ENV_REWARD_OLD_STATE) {  // humanoid.py:195,264-311: every term from the state BEFORE the step
       // (parked in this env's metrics row across the substeps: six values kept in registers over the whole physics would
       // raise the kernel's register allocation past two waves per SIMD)
-      const RewardTerms r0 = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, st.com1 + (size_t)e * 3, gqfrc_act(), gxpos(), ac);
+      const RewardTerms r0 = reward_terms(clip, old_frame, s + LO(qpos), s + LO(qvel), st.com1 + (size_t)e * 3, gqfrc_act(), gxpos(), ac);
       VNL_SERIAL {
         vreal* mt = st.metrics + (size_t)e * 7;
         mt[0] = r0.rcom, mt[1] = r0.rvel, mt[2] = r0.rquat, mt[3] = r0.ract, mt[4] = r0.rapp, mt[5] = r0.healthy;
@@ -2684,7 +2689,7 @@ struct EnvWave {
     }
     VNL_PROF(29);  // tables, state load, rtrunk
     for (int f = 0; f < ev.n_frames; f++) {
-      fresh().with_trace(trace_of(trace_base, f)).forward(f == 0 ? gw : s + L.qacc);
+      fresh().with_trace(trace_of(trace_base, f)).forward(f == 0 ? gw : s + LO(qacc));
       if (dump_mid && f == ev.n_frames - 1) dump(dump_mid);  // the LDS image as the last forward pass leaves it
       fresh().euler();
     }
@@ -2692,7 +2697,7 @@ struct EnvWave {
     VNL_SYNC_GLOBAL();  // (the glue reads xpos / xquat / qfrc_actuator of the last forward pass across lanes)
     RewardTerms rw;
     if (!(ev.flags & VNL_ENV_REWARD_OLD_STATE)) {  // rodent.py:195: _calculate_reward(state, data) -- the NEW data
-      rw = reward_terms(clip, old_frame, s + L.qpos, s + L.qvel, s + L.com, gqfrc_act(), gxpos(), ac);
+      rw = reward_terms(clip, old_frame, s + LO(qpos), s + LO(qvel), s + LO(com), gqfrc_act(), gxpos(), ac);
     } else {
       const vreal* mt = st.metrics + (size_t)e * 7;
       rw = RewardTerms{mt[0], mt[1], mt[2], mt[3], mt[4], mt[5]};
@@ -2724,9 +2729,12 @@ struct EnvWave {
     prof_end();
   }
 
-  // bisection hook: copy this env's LDS image to a global dump [env][L.total]
+  // bisection hook: copy this env's LDS image to a global dump [env][LO(total)]
   VNL_HD void dump(vreal* out) const {
     VNL_SYNC();
-    VNL_FOR(k, L.total) out[(size_t)e * L.total + k] = s[k];
+    VNL_FOR(k, LO(total)) out[(size_t)e * LO(total) + k] = s[k];
   }
 };
+#undef MI
+#undef LO
+typedef EnvWaveT<VnlSpecGeneric> EnvWave;

@@ -106,6 +106,7 @@ struct vnl_env {
   vreal* dump = nullptr;  // [B][L.total] image of the per-env LDS, written only when debug is on
   int* trace = nullptr;   // [B][n_frames][VNL_TRACE_INTS] solver decisions, written only when debug is on
   int debug = 0;          // 0 off, 1 image at the end of reset / step, 2 image after the last forward pass of a step
+  int spec = 0;           // 1: the kernels specialised for the rodent's dims and layout (VnlSpecRodent) run this env
   size_t lds_bytes = 0;
   int blocks_per_cu = 0;
   std::vector<void*> allocs;
@@ -509,52 +510,50 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   return VNL_OK;
 }
 
-static int imax(int a, int b) { return a > b ? a : b; }
+static VnlDims dims_of(const DevModel& d) {
+  return VnlDims{d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ncg, d.ncon, d.nlimit, d.nefc, d.nM, d.iterations, d.ls_iterations, d.eulerdamp,
+                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton};
+}
 
 static void layout(vnl_env* env) {
   const DevModel& d = env->dm;
-  WsLayout& L = env->L;
-  int o = 0;
-  auto sec = [&](const char* name, int n) {
-    int at = o;
-    env->sections[name] = {at, n};
-    o += n;
-    return at;
-  };
-  auto words = [](size_t bytes) { return (int)((bytes + sizeof(vreal) - 1) / sizeof(vreal)); };
-  L.qpos = sec("qpos", d.nq), L.qvel = sec("qvel", d.nv), L.act = sec("act", d.nu), L.ctrl = sec("ctrl", d.nu);
-  L.actdot = sec("act_dot", d.nu), L.com = sec("subtree_com1", 4);
-  L.cdof = sec("cdof", 6 * d.nv), L.LD = sec("qLD", imax(d.nM, 6 * (d.nv + 1) + 6 * (d.nbody + 1)))  /* also holds the dof / body prefix sums of bias_forces */, L.dinv = sec("qLDiagInv", d.nv);
-  // solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul
-  int pool = imax(imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
-  if (d.eulerdamp) pool = imax(pool, d.nM + d.nv);  // euler() brings the second factor of the substep back into the pool
-  L.P = sec("pool", pool);
-  L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
-  L.pair_room = (L.P + 16 * d.nbody) - L.LD;  // bias_forces keeps cvel at pool + 16 nbody until make_constraint has read it
-  env->sections["efc_D"] = {L.efc_D, d.nefc}, env->sections["Jaref"] = {L.Jaref, d.nefc};
-  env->sections["jv"] = {L.jv, d.nefc};
-  L.smooth = sec("qfrc_smooth", d.nv), L.qacc_smooth = sec("qacc_smooth", d.nv), L.qacc = sec("qacc", d.nv);
-  L.Ma = sec("Ma", d.nv), L.grad = sec("grad", d.nv), L.Mgrad = sec("Mgrad", d.nv), L.search = sec("search", d.nv);
-  L.mv = sec("mv", d.nv), L.qfrc_c = sec("qfrc_constraint", d.nv), L.tmp = sec("tmp", d.nv), L.tmp2 = sec("tmp2", d.nv);
-  L.con_r = sec("con_r", 3 * d.ncon), L.con_t1 = sec("con_t1", 3 * d.ncg);
-  L.tab_anc = sec("tab_anc", words(d.nM)), L.tab_madr = sec("tab_madr", words(6 * (size_t)d.nv));  // row start | row end | descendants, 16 bit each
-  L.tab_body = sec("tab_body", words(3 * (size_t)d.nbody + 2 * (size_t)d.ncon));
-  L.tab_jump = sec("tab_jump", words((size_t)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
-  L.tab_lvl = sec("tab_lvl", words((size_t)d.nv + d.max_depth + 2));
-  L.act_list = sec("act_list", words(4 * (size_t)((d.ncon + 3) / 4) + 8 + 2 * VNL_LIVE_MAX));  // active contacts | their count | existing rows: count, list
-  L.newt_M = L.newt_H = L.newt_J = 0;
+  const WsLayout L = vnl_make_layout(dims_of(d));  // (csrc/vnl_types.h: the same function gives a specialised kernel its constants)
+  env->L = L;
+  auto sec = [&](const char* name, int at, int n) { env->sections[name] = {at, n}; };
+  sec("qpos", L.qpos, d.nq), sec("qvel", L.qvel, d.nv), sec("act", L.act, d.nu), sec("ctrl", L.ctrl, d.nu);
+  sec("act_dot", L.actdot, d.nu), sec("subtree_com1", L.com, 4), sec("cdof", L.cdof, 6 * d.nv);
+  sec("qLD", L.LD, L.dinv - L.LD), sec("qLDiagInv", L.dinv, d.nv), sec("pool", L.P, L.smooth - L.P);
+  sec("efc_D", L.efc_D, d.nefc), sec("Jaref", L.Jaref, d.nefc), sec("jv", L.jv, d.nefc);
+  sec("qfrc_smooth", L.smooth, d.nv), sec("qacc_smooth", L.qacc_smooth, d.nv), sec("qacc", L.qacc, d.nv);
+  sec("Ma", L.Ma, d.nv), sec("grad", L.grad, d.nv), sec("Mgrad", L.Mgrad, d.nv), sec("search", L.search, d.nv);
+  sec("mv", L.mv, d.nv), sec("qfrc_constraint", L.qfrc_c, d.nv), sec("tmp", L.tmp, d.nv), sec("tmp2", L.tmp2, d.nv);
+  sec("con_r", L.con_r, 3 * d.ncon), sec("con_t1", L.con_t1, 3 * d.ncg);
+  sec("tab_anc", L.tab_anc, L.tab_madr - L.tab_anc), sec("tab_madr", L.tab_madr, L.tab_body - L.tab_madr);
+  sec("tab_body", L.tab_body, L.tab_jump - L.tab_body), sec("tab_jump", L.tab_jump, L.tab_lvl - L.tab_jump);
+  sec("tab_lvl", L.tab_lvl, L.act_list - L.tab_lvl);
+  sec("act_list", L.act_list, vnl_words(4 * (long)((d.ncon + 3) / 4) + 8 + 2 * VNL_LIVE_MAX));
   if (d.solver_newton) {
-    L.newt_M = sec("newton_qM", d.nv * d.nv), L.newt_H = sec("newton_H", d.nv * d.nv);
-    L.newt_J = sec("newton_efc_J", d.nefc * d.nv);
+    sec("newton_qM", L.newt_M, d.nv * d.nv), sec("newton_H", L.newt_H, d.nv * d.nv), sec("newton_efc_J", L.newt_J, d.nefc * d.nv);
   }
 #ifdef VNL_PROFILE
-  o = (o + 1) & ~1;
-  L.prof = sec("prof", 2 * (VNL_NPROF + 1));
+  sec("prof", L.prof, 2 * (VNL_NPROF + 1));
 #endif
-  L.total = (o + 3) & ~3;
 }
 
-__global__ void vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action, vreal* dump, vreal* dump_mid, int* trace);
+static bool same_layout(const WsLayout& a, const WsLayout& b) { return memcmp(&a, &b, sizeof(WsLayout)) == 0; }
+static bool same_dims(const VnlDims& a, const VnlDims& b) { return memcmp(&a, &b, sizeof(VnlDims)) == 0; }
+
+// (VNL_KERNEL_ATTR: empty in the product; csrc/build.py --spill sets a VGPR cap to force register spills to scratch,
+// the regression build for the "results must not depend on spilling" test.  VNL_SPEC_ATTR: the specialised instantiations
+// are held to the two waves per SIMD of the generic kernel -- with every bound a constant the compiler unrolls further and
+// would take a 257th register, i.e. half the occupancy)
+#ifndef VNL_KERNEL_ATTR
+#define VNL_KERNEL_ATTR
+#endif
+#define VNL_ENV_KERNEL __launch_bounds__(64) VNL_KERNEL_ATTR
+template <class SP>
+__global__ void VNL_ENV_KERNEL vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action, vreal* dump, vreal* dump_mid,
+                                               int* trace);
 
 extern "C" void vnl_env_destroy(vnl_env* env) {
   if (!env) return;
@@ -630,6 +629,11 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
     e.fac2 = (vreal*)p;
   }
   layout(env);
+  // a model whose every dimension and LDS offset equals the compile-time constants of a specialised kernel runs that kernel
+  env->spec = (same_dims(dims_of(env->dm), VnlSpecRodent::D) && same_layout(env->L, VnlSpecRodent::L)) ? 1 : 0;
+#ifdef VNL_NO_SPEC
+  env->spec = 0;
+#endif
   env->lds_bytes = (size_t)env->L.total * sizeof(vreal);
 #ifdef VNL_STAGE_KNOBS
   if (const char* padk = getenv("VNL_DBG_LDS_BYTES")) {  // occupancy experiments only: force a larger LDS request
@@ -655,7 +659,7 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   }
   {
     int nb_ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, vnl_step_kernel, 64, env->lds_bytes) == hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, vnl_step_kernel<VnlSpecGeneric>, 64, env->lds_bytes) == hipSuccess)
       env->blocks_per_cu = nb_;
   }
   {
@@ -717,25 +721,22 @@ extern "C" int vnl_env_debug(vnl_env* env, int32_t enable, int32_t* row_stride) 
 // ----------------------------------------------------------------------------- kernels
 // One env per 64-lane workgroup; the env's whole working set lives in dynamic LDS (~25 KB ->
 // 6 workgroups per CU, 1536 envs in flight on 256 CUs).
-// (VNL_KERNEL_ATTR: empty in the product; csrc/build.py --spill sets a VGPR cap to force register spills to scratch,
-// the regression build for the "results must not depend on spilling" test)
-#ifndef VNL_KERNEL_ATTR
-#define VNL_KERNEL_ATTR
-#endif
-__global__ void __launch_bounds__(64) VNL_KERNEL_ATTR vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action,
+template <class SP>
+__global__ void VNL_ENV_KERNEL vnl_step_kernel(const KernelConsts* kc, DevState st, const vreal* action,
                                                       vreal* dump, vreal* dump_mid, int* trace) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
+  EnvWaveT<SP> w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
   w.step(action, dump_mid, trace);
   if (dump) w.dump(dump);
 }
 
-__global__ void __launch_bounds__(64) VNL_KERNEL_ATTR vnl_reset_kernel(const KernelConsts* kc, DevState st, const int* start_frame,
+template <class SP>
+__global__ void VNL_ENV_KERNEL vnl_reset_kernel(const KernelConsts* kc, DevState st, const int* start_frame,
                                                        const vreal* noise, vreal* dump, int* trace) {
   VNL_LDS_DECL(lds);
   const VNL_CAS KernelConsts* k = VNL_TO_CAS(KernelConsts, kc);
-  EnvWave w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
+  EnvWaveT<SP> w{k->m, k->ev, st, k->L, lds, blockIdx.x, threadIdx.x, k, nullptr};
   w.reset(start_frame, noise, trace);
   if (dump) w.dump(dump);
 }
@@ -771,9 +772,14 @@ extern "C" int vnl_env_reset(vnl_env* env, const int32_t* start_frame, const flo
   if (rc != VNL_OK) return rc;
   DeviceGuard guard(env->device);  // the launch goes to the env's GPU whatever the caller's current device is
   if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
-  hipLaunchKernelGGL(vnl_reset_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
-                     (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise, env->debug ? env->dump : nullptr,
-                     env->debug ? env->trace : nullptr);
+  if (env->spec)
+    hipLaunchKernelGGL((vnl_reset_kernel<VnlSpecRodent>), dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                       (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise,
+                       env->debug ? env->dump : nullptr, env->debug ? env->trace : nullptr);
+  else
+    hipLaunchKernelGGL((vnl_reset_kernel<VnlSpecGeneric>), dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                       (const KernelConsts*)env->kc, ds, (const int*)start_frame, (const vreal*)noise,
+                       env->debug ? env->dump : nullptr, env->debug ? env->trace : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }
@@ -798,9 +804,14 @@ extern "C" int vnl_env_step(vnl_env* env, const float* action, const vnl_state* 
   if (rc != VNL_OK) return rc;
   DeviceGuard guard(env->device);
   if (!guard.ok) return fail(VNL_ERR_HIP, "hipSetDevice failed");
-  hipLaunchKernelGGL(vnl_step_kernel, dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
-                     (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug == 1 ? env->dump : nullptr,
-                     env->debug == 2 ? env->dump : nullptr, env->debug ? env->trace : nullptr);
+  if (env->spec)
+    hipLaunchKernelGGL((vnl_step_kernel<VnlSpecRodent>), dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                       (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug == 1 ? env->dump : nullptr,
+                       env->debug == 2 ? env->dump : nullptr, env->debug ? env->trace : nullptr);
+  else
+    hipLaunchKernelGGL((vnl_step_kernel<VnlSpecGeneric>), dim3(env->B), dim3(64), env->lds_bytes, (hipStream_t)stream,
+                       (const KernelConsts*)env->kc, ds, (const vreal*)action, env->debug == 1 ? env->dump : nullptr,
+                       env->debug == 2 ? env->dump : nullptr, env->debug ? env->trace : nullptr);
   HIPCHK(hipGetLastError());
   return VNL_OK;
 }

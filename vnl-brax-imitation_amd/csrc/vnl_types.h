@@ -115,6 +115,80 @@ struct WsLayout {
   int total;
 };
 
+/* The integers the per-env LDS layout and the loop bounds of the kernels depend on. */
+struct VnlDims {
+  int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
+  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton;
+};
+
+/* The LDS layout as a function of the dims: evaluated by the host at env creation and, for a model the kernels are
+ * SPECIALISED for (VnlSpecRodent below), at compile time -- every offset then is an immediate of the LDS instructions. */
+#ifndef VNL_NPROF_SLOTS
+#ifdef VNL_PROFILE
+#define VNL_NPROF_SLOTS (2 * (40 + 1))
+#else
+#define VNL_NPROF_SLOTS 0
+#endif
+#endif
+constexpr int vnl_imax(int a, int b) { return a > b ? a : b; }
+constexpr int vnl_words(long bytes) { return (int)((bytes + (long)sizeof(vreal) - 1) / (long)sizeof(vreal)); }
+constexpr WsLayout vnl_make_layout(const VnlDims& d) {
+  WsLayout L{};
+  int o = 0;
+  auto sec = [&o](int n) {
+    int at = o;
+    o += n;
+    return at;
+  };
+  L.qpos = sec(d.nq), L.qvel = sec(d.nv), L.act = sec(d.nu), L.ctrl = sec(d.nu);
+  L.actdot = sec(d.nu), L.com = sec(4);
+  L.cdof = sec(6 * d.nv);
+  L.LD = sec(vnl_imax(d.nM, 6 * (d.nv + 1) + 6 * (d.nbody + 1))); /* also holds the dof / body prefix sums of bias_forces */
+  L.dinv = sec(d.nv);
+  /* solve phase: efc_D | Jaref | jv, then the larger of the contact-wrench prefix sums and the dof prefix sums of jac_mul */
+  int pool = vnl_imax(vnl_imax(14 * d.nbody, 22 * d.nbody), 3 * d.nefc + vnl_imax(6 * (d.ncon + 1), 6 * (d.nv + 1)));
+  if (d.eulerdamp) pool = vnl_imax(pool, d.nM + d.nv); /* euler() brings the second factor of the substep back into the pool */
+  L.P = sec(pool);
+  L.efc_D = L.P, L.Jaref = L.P + d.nefc, L.jv = L.P + 2 * d.nefc;
+  L.pair_room = (L.P + 16 * d.nbody) - L.LD; /* bias_forces keeps cvel at pool + 16 nbody until make_constraint has read it */
+  L.smooth = sec(d.nv), L.qacc_smooth = sec(d.nv), L.qacc = sec(d.nv);
+  L.Ma = sec(d.nv), L.grad = sec(d.nv), L.Mgrad = sec(d.nv), L.search = sec(d.nv);
+  L.mv = sec(d.nv), L.qfrc_c = sec(d.nv), L.tmp = sec(d.nv), L.tmp2 = sec(d.nv);
+  L.con_r = sec(3 * d.ncon), L.con_t1 = sec(3 * d.ncg);
+  L.tab_anc = sec(vnl_words(d.nM)), L.tab_madr = sec(vnl_words(6 * (long)d.nv)); /* row start | row end | descendants, 16 bit each */
+  L.tab_body = sec(vnl_words(3 * (long)d.nbody + 2 * (long)d.ncon));
+  L.tab_jump = sec(vnl_words((long)(d.jump_rounds > 0 ? d.jump_rounds : 1) * d.nbody));
+  L.tab_lvl = sec(vnl_words((long)d.nv + d.max_depth + 2));
+  L.act_list = sec(vnl_words(4 * (long)((d.ncon + 3) / 4) + 8 + 2 * VNL_LIVE_MAX)); /* active contacts | their count | existing rows: count, list */
+  L.newt_M = L.newt_H = L.newt_J = 0;
+  if (d.solver_newton) {
+    L.newt_M = sec(d.nv * d.nv), L.newt_H = sec(d.nv * d.nv);
+    L.newt_J = sec(d.nefc * d.nv);
+  }
+  if (VNL_NPROF_SLOTS) {
+    o = (o + 1) & ~1;
+    L.prof = sec(VNL_NPROF_SLOTS);
+  }
+  L.total = (o + 3) & ~3;
+  return L;
+}
+
+/* Compile-time model of a kernel specialisation.  `fixed == false`: every dimension and LDS offset is read from the constant
+ * block at run time (any model the library accepts).  `fixed == true`: they are the constants below -- loop bounds fold,
+ * LDS offsets become instruction immediates, the scalar loads and address arithmetic of the generic kernel disappear; the
+ * library selects such a kernel only for an env whose dims and layout EQUAL the constants (vnl_env_create checks). */
+struct VnlSpecGeneric {
+  static constexpr bool fixed = false;
+  static constexpr VnlDims D{};
+  static constexpr WsLayout L{};
+};
+/* the reference's rodent (assets/rodent.xml as envs/rodent.py:39-63 compiles it), CG 6 / 6 */
+struct VnlSpecRodent {
+  static constexpr bool fixed = true;
+  static constexpr VnlDims D{74, 73, 30, 66, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 6, 36, 6 | (13 << 8), 0};
+  static constexpr WsLayout L = vnl_make_layout(D);
+};
+
 /* Everything the env kernels read that does not change between launches, in one device buffer.  The kernels read
  * it through the CONSTANT address space (scalar loads at the point of use) instead of taking ~350 SGPRs' worth of
  * by-value kernel arguments, which the compiler kept alive across the whole kernel by spilling them to VGPR lanes. */
