@@ -73,6 +73,14 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_ROWGETI(name, q, l) name[q]
 #define VNL_ROWGETF(expr, q, l) (expr)
 #define VNL_WAVE_FENCE()
+// segment sums of blk_apply: the device's shift-and-add steps on the 64 'lanes' of the array (ascending l: lane l + k still
+// holds the previous step's value when lane l reads it, as in the simultaneous DPP step; shifts stay inside rows of 16)
+#define VNL_SEG_SUM(part, dsc, steps)                                                      \
+  do {                                                                                     \
+    for (int k_ = 0; k_ < (steps); k_++)                                                   \
+      for (int l_ = 0; l_ < 64; l_++)                                                      \
+        if (((dsc)[l_] >> (28 + k_)) & 1u) (part)[l_] += ((l_ & 15) + (1 << k_) < 16) ? (part)[l_ + (1 << k_)] : 0; \
+  } while (0)
 #define VNL_COUNT(pred) ((pred) ? 1 : 0)
 #define VNL_RANK(pred, run, rank) do { rank = run; if (pred) run++; } while (0)
 #define VNL_LINE_HEADERS(out, base, stride) \

@@ -107,6 +107,22 @@ VNL_HD float vnl_wave_scan(float x) {
 // value that lane l holds for its q-th item (rows are dealt out as item = lane + 64 q)
 #define VNL_ROWGETI(name, q, l) __builtin_amdgcn_readlane(name[q], l)
 #define VNL_ROWGETF(expr, q, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, expr), l))
+// sum over the lanes of a SEGMENT of adjacent lanes inside one 16-lane DPP row, left in the segment's first lane (blk_apply):
+// step k adds the value of lane + 2^k where the mask bit (cont >> k) & 1 says that lane still belongs to the segment
+VNL_HD float vnl_seg_sum(float x, unsigned cont, int steps) {
+#define VNL_DPP_SEG(ctrl, bit)                                                                                          \
+  do {                                                                                                                  \
+    const float t_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true)); \
+    x += (cont & (bit)) ? t_ : 0.0f;                                                                                     \
+  } while (0)
+  if (steps > 0) VNL_DPP_SEG(0x101, 1u);  // row_shl:1
+  if (steps > 1) VNL_DPP_SEG(0x102, 2u);  // row_shl:2
+  if (steps > 2) VNL_DPP_SEG(0x104, 4u);  // row_shl:4
+  if (steps > 3) VNL_DPP_SEG(0x108, 8u);  // row_shl:8
+#undef VNL_DPP_SEG
+  return x;
+}
+#define VNL_SEG_SUM(part, dsc, steps) (part = vnl_seg_sum(part, (dsc) >> 28, steps))
 // orders the LDS accesses of the lanes of ONE wave (its LDS operations execute in issue order): no instruction
 #define VNL_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 // out[k] = (int)base[k * stride] for k < VNL_FAC_LINES: lane k loads, v_readlane broadcasts
@@ -1411,8 +1427,87 @@ struct EnvWaveT {
     VNL_SYNC();
   }
 
+  // The same two products, BALANCED: a lane per row (column) makes the wave wait for the deepest row (35 entries for the
+  // rodent, the mean is 14) and the largest subtree (72, same mean).  The host cuts every row / column into blocks of <= 8
+  // entries and deals the blocks out over the lanes (m.blk_tab, csrc/vnl_lib.hip); the blocks of one row sit in adjacent
+  // lanes of a 16-lane DPP row, their partial sums meet in the first of them by shifts (VNL_SEG_SUM) and that lane writes
+  // the element: 3 trips per product for the rodent instead of 5 (rows) and 10 (columns).
+  //   COL == false: out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]          COL == true: out[a] = in[a] + sum_{i in desc(a)} A(i, a) in[i]
+  //   dmode: 0 none, 1 multiply by dinv, 2 divide by dinv
+  template <int ST, bool COL>
+  VNL_HD void blk_apply(int in, int out, int dmode, int LDb, int dinvb) const {
+    const int cfg = MI(blk_cfg);
+    const int trips = COL ? (cfg >> 4) & 15 : cfg & 15, steps = COL ? (cfg >> 12) & 15 : (cfg >> 8) & 15;
+    const unsigned* tab = m.blk_tab + (COL ? (cfg & 15) * 64 : 0);
+    constexpr int W = 8, MAXT = 4;  // (the host builds no table that needs more trips)
+#ifdef __HIP_DEVICE_COMPILE__
+    unsigned pre[MAXT];  // every trip's descriptor requested before the first is used: one exposed global-memory round trip per product
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) pre[t] = t < trips ? tab[t * 64 + (int)lane] : 0u;
+#endif
+#pragma unroll
+    for (int trip = 0; trip < MAXT; trip++) {
+      if (trip >= trips) break;
+      VNL_PERLANE(vreal, part);
+      VNL_PERLANE(unsigned, dsc);
+      VNL_FOR(l, VNL_WAVE_ITEMS(64)) {
+#ifdef __HIP_DEVICE_COMPILE__
+        const unsigned d = pre[trip];
+#else
+        const unsigned d = tab[trip * 64 + l];
+#endif
+        const int n = (int)(d >> 16) & 15;
+        // (entries past the block's own n are read -- they are inside the LDS image: the next row's entries, the next
+        // table -- and dropped by the selects below, which costs less than clamping every index)
+        vreal l_[W], x[W];
+        if constexpr (!COL) {
+          const int e0 = (int)(d & 0xffffu);
+          const unsigned char* an = (const unsigned char*)(s + LO(tab_anc)) + e0;
+          const vreal* row = s + LDb + ST * e0;
+          int j[W];
+#pragma unroll
+          for (int u = 0; u < W; u++) j[u] = an[u], l_[u] = row[ST * u];
+#pragma unroll
+          for (int u = 0; u < W; u++) x[u] = s[in + j[u]];
+        } else {
+          const int i0 = (int)(d & 0x7fu), da = (int)(d >> 7) & 0x3f;
+          const unsigned short* ea = (const unsigned short*)(s + LO(tab_madr)) + MI(nv) + i0;
+          const vreal* ld = s + LDb - ST * da;
+          int e[W];
+#pragma unroll
+          for (int u = 0; u < W; u++) e[u] = ea[u], x[u] = s[in + i0 + u];
+#pragma unroll
+          for (int u = 0; u < W; u++) l_[u] = ld[ST * e[u]];
+        }
+        vreal p0 = vreal(0.), p1 = vreal(0.);
+#pragma unroll
+        for (int u = 0; u < W; u += 2) {
+          p0 += u < n ? l_[u] * x[u] : vreal(0.);
+          p1 += u + 1 < n ? l_[u + 1] * x[u + 1] : vreal(0.);
+        }
+        VNL_AT(part, l) = p0 + p1;
+        VNL_AT(dsc, l) = d;
+      }
+      VNL_SEG_SUM(part, dsc, steps);
+      VNL_FOR(l, VNL_WAVE_ITEMS(64)) {
+        const unsigned d = VNL_AT(dsc, l);
+        if (d & (1u << 27)) {
+          const int r = (int)(d >> 20) & 0x7f;
+          const vreal acc = s[in + r] + VNL_AT(part, l);
+          s[out + r] = dmode == 1 ? acc * s[dinvb + ST * r] : (dmode == 2 ? acc / s[dinvb + ST * r] : acc);
+        }
+      }
+    }
+    VNL_SYNC();
+  }
+
   // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
   VNL_HD void solve_inplace(int x, int LDb, int dinvb) const {
+    if (MI(blk_cfg)) {
+      blk_apply<1, true>(x, LO(tmp2), 1, LDb, dinvb);
+      blk_apply<1, false>(LO(tmp2), x, 0, LDb, dinvb);
+      return;
+    }
     col_apply(x, LO(tmp2), 1, LDb, dinvb);
     row_apply(LO(tmp2), x, false, LDb, dinvb);
   }
@@ -1431,6 +1526,11 @@ struct EnvWaveT {
 
   // out = M v from system 1 of the INTERLEAVED pair factor_pair leaves: (L1, L2) entry pairs at R2 + 2 k, (1/D1, 1/D2) at DV + 2 a
   VNL_HD void mass_mul_pair(int vec, int out, int R2, int DV) const {
+    if (MI(blk_cfg)) {
+      blk_apply<2, false>(vec, LO(tmp2), 2, R2, DV);
+      blk_apply<2, true>(LO(tmp2), out, 0, R2, DV);
+      return;
+    }
     VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[vec + i] + row_dot<2>(adr, dep, vec, R2);

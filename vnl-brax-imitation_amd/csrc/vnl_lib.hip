@@ -444,6 +444,65 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       if ((rc = upload<unsigned char, unsigned char>(env, match, &dp)) != VNL_OK) return rc;
       d.fac_match = dp;
     }
+    {  // EnvWave::blk_apply: the sparse products with the factor / its inverse cut into blocks of <= 8 entries of ONE row (or
+       // column), dealt out so that every lane has about the same number -- the rows of a tree are as long as the dofs are deep
+       // (0 .. 35 for the rodent) and its columns as long as the subtrees are large (0 .. 72): a lane per row / column
+       // makes the wave wait for the longest.  The blocks of a row sit in adjacent lanes of one 16-lane DPP row (their partial
+       // sums are combined by shifts), `trips` x 64 descriptors per form:
+       //   bits 0-15 payload (row form: index of the block's first entry; column form: first descendant | depth of the column << 7)
+       //   16-19 entries in the block | 20-26 row / column | 27 first block of its row | 28-31 lane + 1, 2, 4, 8 continues the row
+      d.blk_tab = nullptr, d.blk_cfg = 0;
+      auto pack = [&](bool colform, std::vector<unsigned>& out, int& trips, int& steps) -> bool {
+        struct Item { int r, nblk; };
+        std::vector<Item> items;
+        int total = 0, longest = 1;
+        for (int r = 0; r < nv; r++) {
+          const int len = colform ? ndesc[r] : depth[r], nb_ = len > 0 ? (len + 7) / 8 : 1;
+          if (nb_ > 16) return false;
+          items.push_back({r, nb_}), total += nb_, longest = nb_ > longest ? nb_ : longest;
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.nblk > b.nblk; });
+        steps = longest > 8 ? 4 : (longest > 4 ? 3 : (longest > 2 ? 2 : (longest > 1 ? 1 : 0)));
+        for (trips = (total + 63) / 64; trips <= 8; trips++) {
+          std::vector<int> fill(trips * 4, 0);
+          std::vector<unsigned> tab((size_t)trips * 64, 0u);
+          bool ok = true;
+          for (const Item& it : items) {
+            int bin = -1;
+            for (int b = 0; b < trips * 4 && bin < 0; b++)
+              if (fill[b] + it.nblk <= 16) bin = b;
+            if (bin < 0) { ok = false; break; }
+            const int len = colform ? ndesc[it.r] : depth[it.r];
+            for (int k = 0; k < it.nblk; k++) {
+              const int slot = bin * 16 + fill[bin] + k, left = it.nblk - 1 - k;  // blocks of the row after this one
+              const int n = len - 8 * k > 8 ? 8 : (len - 8 * k > 0 ? len - 8 * k : 0);
+              unsigned payload;
+              if (colform) payload = (unsigned)(n > 0 ? it.r + 1 + 8 * k : it.r) | ((unsigned)depth[it.r] << 7);
+              else payload = (unsigned)(madr[it.r] + (n > 0 ? 1 + 8 * k : 0));
+              unsigned mask = 0;
+              for (int b = 0; b < 4; b++)
+                if ((1 << b) <= left) mask |= 1u << b;
+              tab[slot] = payload | ((unsigned)n << 16) | ((unsigned)it.r << 20) | ((k == 0 ? 1u : 0u) << 27) | (mask << 28);
+            }
+            fill[bin] += it.nblk;
+          }
+          if (ok) {
+            out = tab;
+            return true;
+          }
+        }
+        return false;
+      };
+      std::vector<unsigned> rowtab, coltab;
+      int tr = 0, tc = 0, sr = 0, sc = 0;
+      if (nv <= 127 && maxd <= 63 && d.nM < 65536 && pack(false, rowtab, tr, sr) && pack(true, coltab, tc, sc)) {
+        rowtab.insert(rowtab.end(), coltab.begin(), coltab.end());
+        const unsigned* dp = nullptr;
+        if ((rc = upload<unsigned, unsigned>(env, rowtab, &dp)) != VNL_OK) return rc;
+        d.blk_tab = dp;
+        d.blk_cfg = tr | (tc << 4) | (sr << 8) | (sc << 12);
+      }
+    }
   }
   UPF(dof_armature, F("dof_armature")) UPF(dof_damping, F("dof_damping"))
   UPI(act_dof, I("act_dof")) UPI(act_limited, I("act_ctrllimited")) UPF(act_gain, F("act_gain"))
@@ -512,7 +571,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
 
 static VnlDims dims_of(const DevModel& d) {
   return VnlDims{d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ncg, d.ncon, d.nlimit, d.nefc, d.nM, d.iterations, d.ls_iterations, d.eulerdamp,
-                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton};
+                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton, d.blk_cfg};
 }
 
 static void layout(vnl_env* env) {

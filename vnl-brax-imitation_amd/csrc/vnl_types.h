@@ -38,6 +38,7 @@ struct DevModel {
   int fac_steps; /* number of steps of the factorisation schedule */
   int fac_nleaf; /* low byte: leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand
                     side), else 0; bits 8..: depth of the deepest of the rows 64 .. (second lane set) */
+  int blk_cfg;   /* EnvWave::blk_apply: trips of the row form | trips of the column form << 4 | combine steps (row) << 8 | (column) << 12; 0 = no table */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
   vreal gx, gy, gz;
@@ -63,6 +64,7 @@ struct DevModel {
   const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot; scratch line | one leaf under a << 8 | mask of all leaves under a << 16 */
   const int* fac_guest;              /* [64] row 64.. that rides in lane l's registers during factor_pair_packed (-1: none); null if
                                         the model has no such rows or they cannot be placed (host depth <= 12, guest depth <= 24) */
+  const unsigned* blk_tab;           /* [trips_row x 64 | trips_col x 64] block descriptors of blk_apply (vnl_lib.hip builds them); null if blk_cfg == 0 */
   const unsigned char* fac_match;    /* [nv][fac_steps]: bit k set = row a absorbs the pivot published in scratch line k in that step */
   const int *dof_ndesc;              /* descendants of dof a are dofs a+1 .. a+ndesc[a] (DFS numbering) */
   const unsigned char* lvl_tab;      /* [nv] dofs sorted by depth, then [max_depth+2] level starts */
@@ -118,7 +120,7 @@ struct WsLayout {
 /* The integers the per-env LDS layout and the loop bounds of the kernels depend on. */
 struct VnlDims {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
-  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton;
+  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton, blk_cfg;
 };
 
 /* The LDS layout as a function of the dims: evaluated by the host at env creation and, for a model the kernels are
@@ -185,7 +187,8 @@ struct VnlSpecGeneric {
 /* the reference's rodent (assets/rodent.xml as envs/rodent.py:39-63 compiles it), CG 6 / 6 */
 struct VnlSpecRodent {
   static constexpr bool fixed = true;
-  static constexpr VnlDims D{74, 73, 30, 66, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 6, 36, 6 | (13 << 8), 0};
+  static constexpr VnlDims D{74, 73, 30, 66, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 6, 36, 6 | (13 << 8), 0,
+                             3 | (3 << 4) | (3 << 8) | (4 << 12)};
   static constexpr WsLayout L = vnl_make_layout(D);
 };
 
