@@ -57,31 +57,39 @@ def test_spilling_build_matches_oracle_and_product_build():
     assert all(same.values()), (same, worst)  # bit for bit, as DESIGN section 2 item 3 states
 
 
-def test_packed_factorisation_equals_the_plain_form_bit_for_bit():
-    """factor_pair on the device interleaves the two systems' rows (v_pk_fma_f32) and carries the rows 64.. as guests in
-    other lanes' registers; the plain form (the one the host simulation compiles, csrc/build.py --unpacked) performs the
-    same operations on the same operands in the same order per entry: three control steps must agree bit for bit."""
+def test_blocked_products_agree_with_the_lane_per_row_products():
+    """The products with the factor and its inverse (M^-1 x, M x) run BLOCKED on the device: rows / columns cut into blocks of
+    eight entries dealt out over the lanes, partial sums combined by DPP shifts (EnvWave::blk_apply).  csrc/build.py --noblk
+    builds the same sources with one lane per row / column: the same sums in another order.  One substep from identical
+    states may differ by the rounding of those sums and what six CG iterations make of it -- nothing more: the median env
+    within 1e-6 of scale on the velocities, and no more envs beyond 1e-5 than the product has against the float64 oracle."""
     from vnl_brax_imitation_amd import _lib
     from vnl_brax_imitation_amd.csrc import build as hip_build
+    from vnl_brax_imitation_amd.envs.rodent import RodentTracking
 
-    path = hip_build.build(variant="unpacked")
-    B = 512
+    path = hip_build.build(variant="noblk")
+    B = 1024
     rng = np.random.default_rng(33)
     sf = rng.integers(0, 235, B).astype(np.int32)
     noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)
-    acts = np.clip(0.3 * rng.standard_normal((3, B, 30)), -1, 1).astype(np.float32)
+    act = np.clip(0.3 * rng.standard_normal((B, 30)), -1, 1).astype(np.float32)
+    kw = dict(H.env_kwargs(), n_frames=1)
     outs = []
-    for env in (_env(B, _lib.load_library(path)), _env(B)):
+    for lib in (_lib.load_library(path), None):
+        with H.backend(lib):
+            env = RodentTracking(H.reference_clip(), num_envs=B, device="cuda:0", **kw)
         s = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
-        for a in acts:
-            s = env.step(s, torch.from_numpy(a))
-        ps = s.pipeline_state
-        outs.append({k: getattr(ps, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc_warmstart", "xpos")} |
-                    {"obs": s.obs.cpu().numpy().copy(), "reward": s.reward.cpu().numpy().copy()})
-    same = {k: bool(np.array_equal(outs[0][k], outs[1][k])) for k in outs[0]}
-    worst = {k: float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()) for k in outs[0]}
-    print("\n[packed vs plain factor_pair, 3 steps, 512 envs] bitwise equal:", same, "largest difference:", worst)
-    assert all(same.values()), (same, worst)
+        ps0 = {k: getattr(s.pipeline_state, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc_warmstart")}
+        s = env.step(s, torch.from_numpy(act))
+        outs.append((ps0, {k: getattr(s.pipeline_state, k).cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "qacc_warmstart")}))
+    # (the reset runs a forward pass with the products in it: the two builds start the substep from states that agree to rounding)
+    for k in ("qpos", "qvel"):
+        assert P.per_env_grouped(outs[0][0][k].astype(np.float64), outs[1][0][k].astype(np.float64), k).max() < 1e-6, k
+    diff = {k: P.per_env_grouped(outs[0][1][k], outs[1][1][k], k) for k in ("qpos", "qvel", "qacc_warmstart")}
+    print("\n[blocked vs lane-per-row products, one substep, 1024 envs] " +
+          ", ".join(f"{k}: median {np.median(v):.2e} max {v.max():.2e} over 1e-5: {(v > 1e-5).sum()}" for k, v in diff.items()))
+    assert np.median(diff["qvel"]) < 1e-6 and np.median(diff["qpos"]) < 1e-6
+    assert (diff["qvel"] > 1e-5).mean() < 0.08  # (the product against the float64 oracle: 3-4 % of envs, bench.py compliance)
 
 
 def test_specialised_kernels_equal_the_generic_kernels_bit_for_bit():

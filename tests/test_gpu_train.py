@@ -49,7 +49,9 @@ def test_hand_written_update_trains_like_the_autograd_update():
     assert torch.equal(n0.mean, n1.mean)
     d = float((ts0.params - ts1.params).abs().max())
     print(f"\n[hip vs torch update, 8 Adam steps] max |param difference| {d:.2e} (lr 1e-3)")
-    assert d < 5e-5, d  # Adam turns a 1e-6 relative gradient difference into at most ~lr of parameter difference per step
+    # Adam turns a 1e-6 relative gradient difference into at most ~lr of parameter difference per step (8e-3 over these 8);
+    # measured 2e-5 .. 5.5e-5 depending on the rollout the env kernels of the day produce
+    assert d < 1e-4, d
     for k in ("training/total_loss", "training/v_loss", "training/policy_loss", "training/kl_loss_intention"):
         assert abs(m0[k] - m1[k]) <= 1e-4 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
 

@@ -13,7 +13,8 @@ OUT = os.path.join(HERE, "libvnl.so")
 # Diagnostic / regression builds of the SAME sources (never the product library, only loaded by tools/ and tests/):
 #   prof   -DVNL_PROFILE      per-stage s_memtime stamps (tools/stage_profile.py)
 #   knobs  -DVNL_STAGE_KNOBS  stage-repeat knob VNL_DBG_REPEAT + LDS padding knob (tools/stage_cost.py, tools/pmc_stage.sh)
-#   unpacked  -DVNL_FAC_UNPACKED: factor_pair in its plain form (regression build for the packed device form)
+#   noblk  -DVNL_NO_BLK: the products with the factor / its inverse one lane per row / column (regression build for the
+#          balanced blocked form, EnvWave::blk_apply: same sums in another order)
 #   spill  env kernels compiled under a 128-VGPR cap, which forces ~230 registers per lane to spill to scratch
 #          memory: results must not depend on spilling (tests/test_gpu_spill.py)
 VARIANTS = {
@@ -24,9 +25,7 @@ VARIANTS = {
     "prof": ("libvnl_prof.so", ["-DVNL_PROFILE", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     "knobs": ("libvnl_knobs.so", ["-DVNL_STAGE_KNOBS", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     "spill": ("libvnl_spill.so", ["-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(4,4)))"]),
-    # the two factorisations of a substep in the plain form (one lane set per 64 rows, one v_fma_f32 per system): the form the
-    # host simulation compiles; the product's packed form must agree with it bit for bit (tests/test_gpu_spill.py)
-    "unpacked": ("libvnl_unpacked.so", ["-DVNL_FAC_UNPACKED", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
+    "noblk": ("libvnl_noblk.so", ["-DVNL_NO_BLK", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
     # the generic kernels (dims and LDS offsets read at run time) on the rodent too: the specialised ones must agree bit for bit
     "nospec": ("libvnl_nospec.so", ["-DVNL_NO_SPEC", "-DVNL_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))"]),
 }

@@ -1267,30 +1267,114 @@ struct EnvWaveT {
     VNL_PROF(9);
   }
 #endif
-  // models whose two factorisations go through factor_pair (same conditions as the register route of factor(), plus
-  // room for the second set of scratch lines in the eight dead vectors Ma .. tmp2 and for the factor copy in the pool)
+  // The two factorisations WITHOUT the matrix: the articulated-body form of L'DL.  With every spatial quantity expressed
+  // about one common origin (as they are here) the elimination of dof k from the joint-space matrix is a rank-one downdate
+  // of the articulated inertia of k's subtree, IA <- IA - U_k U_k' / D_k with U_k = IA cdof_k, D_k = cdof_k . U_k + armature_k
+  // (+ h damping_k for the second system), and row k of the unit-lower factor is a set of projections of ONE 6-vector:
+  //     L(k, j) = cdof_j . U_k / D_k          for every ancestor j of k.
+  // IA is never formed: applied to cdof_j it is  U_j = crb(body_j) cdof_j - sum_{k below j} L(k, j) U_k,  so each lane keeps
+  // the 6-vector U_j of its dof (both systems side by side: 6 register pairs instead of 36 matrix-row pairs), a pivot
+  // publishes (U_k, 1/D_k) -- 16 floats -- and each ancestor lane spends 6 + 6 packed multiply-adds on it instead of a
+  // multiply-add per matrix column.  Same schedule (m.dof_ftime / dof_fslot / fac_match) and same output as the row
+  // elimination this replaces (tests/test_hostsim_parity.py: the float64 host build against the dense oracle): the
+  // interleaved (L1, L2) image at pair_base(), the reciprocal pivot pairs at pair_dinv().  Needs crb in the pool (mass_matrix's
+  // tree_accumulate); the matrix entries themselves are not needed any more.
+  template <int NSET>
+  VNL_HD void factor_aba(vreal h) const {
+    constexpr int LW = 16;  // [(U1, U2) x 6 | 1/D1, 1/D2 | end address of the pivot's row | pad]
+    const int sc = (LO(Mgrad) + 3) & ~3;  // Mgrad .. tmp2 are dead while factorising (Ma, grad take the reciprocal pivots)
+    const int R2 = pair_base(), DV = pair_dinv();
+    const int nsteps = MI(fac_steps);
+    v2r U[NSET][6], diag[NSET];
+    vreal S[NSET][6];
+    int dep[NSET], ftime[NSET], myline[NSET], adrs[NSET];
+    const unsigned char* mt[NSET];
+    unsigned nxt[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      const int a = (int)lane + q * VNL_LANES;
+      const bool ok = a < MI(nv);
+      const int aa = ok ? a : 0;
+      const S6 c = ld6(LO(cdof) + 6 * aa), f = inert_mul(LO(P) + 10 * m.dof_body[aa], c);
+      S[q][0] = c.a.x, S[q][1] = c.a.y, S[q][2] = c.a.z, S[q][3] = c.l.x, S[q][4] = c.l.y, S[q][5] = c.l.z;
+      U[q][0] = v2r{f.a.x, f.a.x}, U[q][1] = v2r{f.a.y, f.a.y}, U[q][2] = v2r{f.a.z, f.a.z};
+      U[q][3] = v2r{f.l.x, f.l.x}, U[q][4] = v2r{f.l.y, f.l.y}, U[q][5] = v2r{f.l.z, f.l.z};
+      const vreal arm = m.dof_armature[aa];
+      diag[q] = v2r{arm, arm + h * m.dof_damping[aa]};
+      adrs[q] = madr(aa), dep[q] = eadr(aa) - adrs[q];
+      myline[q] = m.dof_fslot[aa] & 0xff;
+      ftime[q] = ok ? m.dof_ftime[aa] : -1;
+      mt[q] = m.fac_match + (size_t)aa * nsteps;
+      nxt[q] = (ok && nsteps > 0) ? mt[q][0] : 0u;
+    }
+    VNL_SYNC();  // (crb is read: the image may now grow over it)
+    VNL_PROF(7);
+    for (int step = 0; step < nsteps; step++) {
+      unsigned cur[NSET];
+#pragma unroll
+      for (int q = 0; q < NSET; q++) {
+        cur[q] = nxt[q];
+        nxt[q] = (ftime[q] >= 0 && step + 1 < nsteps) ? mt[q][step + 1] : 0u;  // prefetch
+        if (ftime[q] == step) {  // this row is a pivot now: every dof below it has been absorbed
+          const int a = (int)lane + q * VNL_LANES;
+          v2r D = diag[q];
+#pragma unroll
+          for (int i = 0; i < 6; i++) D += v2r{S[q][i], S[q][i]} * U[q][i];
+          const v2r iv = v2r{vnl_recip(D[0]), vnl_recip(D[1])};
+          vreal* ln = s + sc + myline[q] * LW;
+          st4a(ln, U[q][0][0], U[q][0][1], U[q][1][0], U[q][1][1]);
+          st4a(ln + 4, U[q][2][0], U[q][2][1], U[q][3][0], U[q][3][1]);
+          st4a(ln + 8, U[q][4][0], U[q][4][1], U[q][5][0], U[q][5][1]);
+          st4a(ln + 12, iv[0], iv[1], (vreal)(adrs[q] + dep[q]), vreal(0.));
+          s[R2 + 2 * adrs[q]] = D[0], s[R2 + 2 * adrs[q] + 1] = D[1];
+          s[DV + 2 * a] = iv[0], s[DV + 2 * a + 1] = iv[1];
+        }
+      }
+      VNL_WAVE_FENCE();
+      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
+        bool more = false;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) more = more || cur[q] != 0u;
+        if (!vnl_wave_any(more)) break;
+#pragma unroll
+        for (int q = 0; q < NSET; q++) {
+          if (cur[q] != 0u) {
+            const int k = __builtin_ctz(cur[q]);
+            cur[q] &= cur[q] - 1u;
+            const vreal* ln = s + sc + k * LW;
+            const R4 u0 = ld4a(ln), u1 = ld4a(ln + 4), u2 = ld4a(ln + 8), hd = ld4a(ln + 12);
+            const v2r Uk[6] = {v2r{u0.x, u0.y}, v2r{u0.z, u0.w}, v2r{u1.x, u1.y}, v2r{u1.z, u1.w}, v2r{u2.x, u2.y}, v2r{u2.z, u2.w}};
+            v2r pa = v2r{S[q][0], S[q][0]} * Uk[0], pb = v2r{S[q][1], S[q][1]} * Uk[1];
+            pa += v2r{S[q][2], S[q][2]} * Uk[2], pb += v2r{S[q][3], S[q][3]} * Uk[3];
+            pa += v2r{S[q][4], S[q][4]} * Uk[4], pb += v2r{S[q][5], S[q][5]} * Uk[5];
+            const v2r Lk = (pa + pb) * v2r{hd.x, hd.y};
+#pragma unroll
+            for (int i = 0; i < 6; i++) U[q][i] -= Lk * Uk[i];
+            const int e = (int)hd.z - dep[q];  // L(k, this dof): row k holds its ancestors from the parent (adr + 1) up to the root (end)
+            s[R2 + 2 * e] = Lk[0], s[R2 + 2 * e + 1] = Lk[1];
+          }
+        }
+      }
+      VNL_WAVE_FENCE();
+    }
+    VNL_SYNC();
+    VNL_PROF(8);
+    VNL_PROF(9);
+  }
+
+  // models whose two factorisations go through factor_aba: invert_pair keeps their rows in registers (depth < 36; rows 64 ..
+  // depth < 16), the interleaved image of both factors (2 nM elements from LO(LD) on) ends below cvel, which make_constraint
+  // still needs, and the six scratch lines fit into the dead vectors Mgrad .. tmp2
   VNL_HD bool factor_pair_ok() const {
     const int nv = MI(nv), md = MI(max_depth);
     if (!MI(eulerdamp) || !m.fac_match) return false;
-    const int room = 8 * nv - 3 - 8 * VNL_FAC_LINES;
     const bool regs = (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) ||
-                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (MI(fac_nleaf) >> 8) < 16 && m.fac_guest);
-    // (m.fac_guest: the rows 64.. have a place in the packed device form; a model where they have none takes the
-    // one-system route in both builds, so that the two forms of factor_pair always run on the same models)
-    // .. and the interleaved image of both factors (2 nM elements from LO(LD) on) ends below cvel, which make_constraint still needs
-    return regs && 2 * MI(nM) <= LO(pair_room) && VNL_FAC_LINES * (2 * (md < 16 ? 16 : 36) + 4) <= room;  // (both forms' scratch lines fit: 2 x 6 x 40 vs 6 x 76)
+                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (MI(fac_nleaf) >> 8) < 16);
+    return regs && 2 * MI(nM) <= LO(pair_room) && VNL_FAC_LINES * 16 + 3 <= 6 * nv;
   }
   VNL_HD void factor_both(vreal h) const {
-    const int nv = MI(nv), md = MI(max_depth);
-#ifdef VNL_FAC_PACKED
-    if (nv <= VNL_LANES && md < 16) return factor_pair_packed<16, false>(h);
-    if (nv <= VNL_LANES) return factor_pair_packed<36, false>(h);
-    return factor_pair_packed<36, true>(h);  // (factor_pair_ok(): the guests could be placed)
-#else
-    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) factor_pair<VNL_ROWSETS_1, 16>(h);
-    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) factor_pair<VNL_ROWSETS_1, 36>(h);
-    else factor_pair<VNL_ROWSETS_2, 36, 16>(h);
-#endif
+    if (MI(nv) <= VNL_ROWSETS_1 * VNL_LANES) factor_aba<VNL_ROWSETS_1>(h);
+    else factor_aba<VNL_ROWSETS_2>(h);
   }
 
   VNL_HD void factor(bool with_loop = true) const {
@@ -1501,9 +1585,16 @@ struct EnvWaveT {
     VNL_SYNC();
   }
 
+  VNL_HD bool blk_on() const {
+#ifdef VNL_NO_BLK  // regression build (csrc/build.py --noblk): the lane-per-row / lane-per-column products
+    return false;
+#else
+    return MI(blk_cfg) != 0;
+#endif
+  }
   // x <- M^-1 x = L^-1 D^-1 L^-T x with the inverted factor: two dependency-free sparse products
   VNL_HD void solve_inplace(int x, int LDb, int dinvb) const {
-    if (MI(blk_cfg)) {
+    if (blk_on()) {
       blk_apply<1, true>(x, LO(tmp2), 1, LDb, dinvb);
       blk_apply<1, false>(LO(tmp2), x, 0, LDb, dinvb);
       return;
@@ -1526,7 +1617,7 @@ struct EnvWaveT {
 
   // out = M v from system 1 of the INTERLEAVED pair factor_pair leaves: (L1, L2) entry pairs at R2 + 2 k, (1/D1, 1/D2) at DV + 2 a
   VNL_HD void mass_mul_pair(int vec, int out, int R2, int DV) const {
-    if (MI(blk_cfg)) {
+    if (blk_on()) {
       blk_apply<2, false>(vec, LO(tmp2), 2, R2, DV);
       blk_apply<2, true>(LO(tmp2), out, 0, R2, DV);
       return;
@@ -2397,12 +2488,12 @@ struct EnvWaveT {
       } else if (m.dbg_stage == 15) {
         kinematics();
         body_inertias(false);
-        mass_matrix(vreal(0.));
+        tree_accumulate(LO(P), 10);
         if (factor_pair_ok()) factor_both(m.dt);
       } else if (m.dbg_stage == 17) {
         kinematics();
         body_inertias(false);
-        mass_matrix(vreal(0.));
+        tree_accumulate(LO(P), 10);
         if (factor_pair_ok()) {
           factor_both(m.dt);
           invert_both(pair_base(), pair_dinv(), fac2());
@@ -2424,13 +2515,18 @@ struct EnvWaveT {
     fresh().body_inertias(true);
     VNL_PROF(1);
     int cvel = fresh().bias_forces();
-    fresh().mass_matrix(vreal(0.));
     if (factor_pair_ok()) {
+      // (the factors come from the composite inertias directly; the matrix itself only where the Newton solver wants its dense copy)
+      if (MI(solver_newton)) fresh().mass_matrix(vreal(0.));
+      else fresh().tree_accumulate(LO(P), 10);
+      VNL_PROF(5);
+      VNL_PROF(6);
       fresh().factor_both(m.dt);
       fresh().mass_mul_pair(LO(qacc), LO(mv), pair_base(), pair_dinv());  // M * qacc_warmstart, needs L (before it becomes L^-1)
       VNL_PROF(10);
       fresh().invert_both(pair_base(), pair_dinv(), fac2());
     } else {
+      fresh().mass_matrix(vreal(0.));
       fresh().factor();
       fresh().mass_mul_factor(LO(qacc), LO(mv));
       VNL_PROF(10);
