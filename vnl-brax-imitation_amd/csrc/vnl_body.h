@@ -1276,14 +1276,16 @@ struct EnvWaveT {
   // the 6-vector U_j of its dof (both systems side by side: 6 register pairs instead of 36 matrix-row pairs), a pivot
   // publishes (U_k, 1/D_k) -- 16 floats -- and each ancestor lane spends 6 + 6 packed multiply-adds on it instead of a
   // multiply-add per matrix column.  Same schedule (m.dof_ftime / dof_fslot / fac_match) and same output as the row
-  // elimination this replaces (tests/test_hostsim_parity.py: the float64 host build against the dense oracle): the
-  // interleaved (L1, L2) image at pair_base(), the reciprocal pivot pairs at pair_dinv().  Needs crb in the pool (mass_matrix's
+  // elimination this replaces (tests/test_hostsim_parity.py: the float64 host build against the dense oracle).  Out: L1 in
+  // LO(LD) and 1/D1 in LO(dinv) (M * qacc_warmstart), V_k = U_k / D_k of both systems in the pool (vstore(): what invert_aba
+  // builds both inverse factors from), 1/D2 in the env's global scratch.  Needs crb in the pool (mass_matrix's
   // tree_accumulate); the matrix entries themselves are not needed any more.
   template <int NSET>
   VNL_HD void factor_aba(vreal h) const {
     constexpr int LW = 16;  // [(U1, U2) x 6 | 1/D1, 1/D2 | end address of the pivot's row | pad]
-    const int sc = (LO(Mgrad) + 3) & ~3;  // Mgrad .. tmp2 are dead while factorising (Ma, grad take the reciprocal pivots)
-    const int R2 = pair_base(), DV = pair_dinv();
+    const int sc = (LO(Mgrad) + 3) & ~3;  // Mgrad .. tmp2 are dead while factorising
+    const int VS = vstore();
+    vreal* g2 = fac2();
     const int nsteps = MI(fac_steps);
     v2r U[NSET][6], diag[NSET];
     vreal S[NSET][6];
@@ -1326,8 +1328,14 @@ struct EnvWaveT {
           st4a(ln + 4, U[q][2][0], U[q][2][1], U[q][3][0], U[q][3][1]);
           st4a(ln + 8, U[q][4][0], U[q][4][1], U[q][5][0], U[q][5][1]);
           st4a(ln + 12, iv[0], iv[1], (vreal)(adrs[q] + dep[q]), vreal(0.));
-          s[R2 + 2 * adrs[q]] = D[0], s[R2 + 2 * adrs[q] + 1] = D[1];
-          s[DV + 2 * a] = iv[0], s[DV + 2 * a + 1] = iv[1];
+          // what stays: V = U / D of both systems (invert_aba), 1/D1 where every M^-1 product expects it, 1/D2 beside N2
+          vreal* vs = s + VS + 12 * a;
+          const v2r v0 = U[q][0] * iv, v1 = U[q][1] * iv, v2 = U[q][2] * iv, v3_ = U[q][3] * iv, v4 = U[q][4] * iv, v5 = U[q][5] * iv;
+          st4a(vs, v0[0], v0[1], v1[0], v1[1]);
+          st4a(vs + 4, v2[0], v2[1], v3_[0], v3_[1]);
+          st4a(vs + 8, v4[0], v4[1], v5[0], v5[1]);
+          s[LO(dinv) + a] = iv[0];
+          g2[MI(nM) + a] = iv[1];
         }
       }
       VNL_WAVE_FENCE();
@@ -1350,8 +1358,8 @@ struct EnvWaveT {
             const v2r Lk = (pa + pb) * v2r{hd.x, hd.y};
 #pragma unroll
             for (int i = 0; i < 6; i++) U[q][i] -= Lk * Uk[i];
-            const int e = (int)hd.z - dep[q];  // L(k, this dof): row k holds its ancestors from the parent (adr + 1) up to the root (end)
-            s[R2 + 2 * e] = Lk[0], s[R2 + 2 * e + 1] = Lk[1];
+            // L1(k, this dof) for M * qacc_warmstart: row k holds its ancestors from the parent (adr + 1) up to the root (end)
+            s[LO(LD) + (int)hd.z - dep[q]] = Lk[0];
           }
         }
       }
@@ -1362,15 +1370,69 @@ struct EnvWaveT {
     VNL_PROF(9);
   }
 
-  // models whose two factorisations go through factor_aba: invert_pair keeps their rows in registers (depth < 36; rows 64 ..
-  // depth < 16), the interleaved image of both factors (2 nM elements from LO(LD) on) ends below cvel, which make_constraint
-  // still needs, and the six scratch lines fit into the dead vectors Mgrad .. tmp2
+  VNL_HD int vstore() const { return (LO(P) + 3) & ~3; }  // [nv][(V1, V2) x 6]: over crb, below cvel (factor_pair_ok)
+
+  // Both inverse factors N = L^-1 from the same 6-vectors: walking up from row k, with C = V_k at the start,
+  //     N(k, j) = -cdof_j . C,     C += N(k, j) V_j          for the parent j, the grandparent, ..
+  // (C is sum_i N(k, i) V_i over the path walked so far, so cdof_j . C = sum_i N(k, i) L(i, j)): 6 + 6 packed multiply-adds
+  // per entry where the row recurrence on matrix entries needs one per entry ALREADY done -- the rodent's deep rows (35
+  // ancestors) cost 420 instead of 612, and nothing depends on a row of registers per lane.  N1 goes to LO(LD) (over L1,
+  // which M * qacc_warmstart has used by then), N2 to the env's global scratch for euler().  A lane takes row `lane`, then
+  // (GUESTS) the row 64.. the host table m.fac_guest places with it -- both inside ONE loop, so that the nine short extra
+  // rows of the rodent ride in the shadow of the deep ones.
+  template <int NSET, bool GUESTS>
+  VNL_HD void invert_aba(vreal* g2) const {
+    const int VS = vstore();
+    const unsigned char* an = (const unsigned char*)(s + LO(tab_anc));
+    auto load_v = [&](int r, v2r* C) {
+      const vreal* vs = s + VS + 12 * r;
+      const R4 a = ld4a(vs), b = ld4a(vs + 4), c = ld4a(vs + 8);
+      C[0] = v2r{a.x, a.y}, C[1] = v2r{a.z, a.w}, C[2] = v2r{b.x, b.y}, C[3] = v2r{b.z, b.w}, C[4] = v2r{c.x, c.y}, C[5] = v2r{c.z, c.w};
+    };
+#pragma unroll
+    for (int q = 0; q < NSET; q++) {
+      const int a = (int)lane + q * VNL_LANES;
+      int row = a < MI(nv) ? a : -1, next = -1;
+      if (GUESTS && q == 0 && m.fac_guest) next = m.fac_guest[lane];
+      int adr = madr(row >= 0 ? row : 0), d = row >= 0 ? eadr(row) - adr : 0, tt = 0;
+      v2r C[6];
+      load_v(row >= 0 ? row : 0, C);
+      int jn = an[adr + (d > 0 ? 1 : 0)];
+      while (vnl_wave_any(row >= 0)) {
+        if (row >= 0 && tt == d) {  // this row is done: on to the guest row, if any
+          row = next, next = -1;
+          if (row >= 0) {
+            adr = madr(row), d = eadr(row) - adr, tt = 0;
+            load_v(row, C);
+            jn = an[adr + (d > 0 ? 1 : 0)];
+          }
+        }
+        if (row >= 0 && tt < d) {
+          const int j = jn;
+          jn = an[adr + (tt + 2 <= d ? tt + 2 : d)];  // the next ancestor's index while this one's vectors arrive
+          const S6 c = ld6(LO(cdof) + 6 * j);
+          v2r V[6];
+          load_v(j, V);
+          v2r pa = v2r{c.a.x, c.a.x} * C[0], pb = v2r{c.a.y, c.a.y} * C[1];
+          pa += v2r{c.a.z, c.a.z} * C[2], pb += v2r{c.l.x, c.l.x} * C[3];
+          pa += v2r{c.l.y, c.l.y} * C[4], pb += v2r{c.l.z, c.l.z} * C[5];
+          const v2r n = -(pa + pb);
+#pragma unroll
+          for (int i = 0; i < 6; i++) C[i] += n * V[i];
+          tt++;
+          s[LO(LD) + adr + tt] = n[0], g2[adr + tt] = n[1];
+        }
+      }
+    }
+    VNL_SYNC();
+  }
+
+  // models whose two factorisations go through factor_aba: the store of the V vectors (12 nv elements from the pool's start) ends
+  // below cvel, which make_constraint still needs, and the six scratch lines fit into the dead vectors Mgrad .. tmp2
   VNL_HD bool factor_pair_ok() const {
-    const int nv = MI(nv), md = MI(max_depth);
+    const int nv = MI(nv);
     if (!MI(eulerdamp) || !m.fac_match) return false;
-    const bool regs = (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 36) ||
-                      (nv <= VNL_ROWSETS_2 * VNL_LANES && md < 36 && (MI(fac_nleaf) >> 8) < 16);
-    return regs && 2 * MI(nM) <= LO(pair_room) && VNL_FAC_LINES * 16 + 3 <= 6 * nv;
+    return nv <= VNL_ROWSETS_2 * VNL_LANES && 12 * nv + 3 <= 16 * MI(nbody) && VNL_FAC_LINES * 16 + 3 <= 6 * nv;
   }
   VNL_HD void factor_both(vreal h) const {
     if (MI(nv) <= VNL_ROWSETS_1 * VNL_LANES) factor_aba<VNL_ROWSETS_1>(h);
@@ -1606,6 +1668,11 @@ struct EnvWaveT {
 
   // out = M v = L' D L v with the (not yet inverted) factor
   VNL_HD void mass_mul_factor(int vec, int out) const {
+    if (blk_on()) {
+      blk_apply<1, false>(vec, LO(tmp2), 2, LO(LD), LO(dinv));
+      blk_apply<1, true>(LO(tmp2), out, 0, LO(LD), LO(dinv));
+      return;
+    }
     VNL_FOR(i, MI(nv)) {
       int adr = madr(i), dep = eadr(i) - adr;
       vreal acc = s[vec + i] + row_dot(adr, dep, vec, LO(LD));
@@ -1695,11 +1762,12 @@ struct EnvWaveT {
     }
     VNL_SYNC();
   }
-  VNL_HD void invert_both(int R2, int DV, vreal* g2) const {
-    const int nv = MI(nv), md = MI(max_depth);
-    if (nv <= VNL_ROWSETS_1 * VNL_LANES && md < 16) invert_pair<VNL_ROWSETS_1, 16>(R2, DV, g2);
-    else if (nv <= VNL_ROWSETS_1 * VNL_LANES) invert_pair<VNL_ROWSETS_1, 36>(R2, DV, g2);
-    else invert_pair<VNL_ROWSETS_2, 36, 16>(R2, DV, g2);
+  VNL_HD void invert_both(vreal* g2) const {
+    if (MI(nv) <= VNL_ROWSETS_1 * VNL_LANES) invert_aba<VNL_ROWSETS_1, false>(g2);
+#if VNL_LANES == 64
+    else if (m.fac_guest) invert_aba<VNL_ROWSETS_1, true>(g2);  // (the rows 64 .. ride with lanes whose own row is short)
+#endif
+    else invert_aba<VNL_ROWSETS_2, false>(g2);
   }
   // where factor_pair leaves the interleaved pair: from LO(LD) on (through LO(dinv) into the pool, below cvel), and the pair of
   // reciprocal pivots in the first two of the eight CG vectors (dead until the solver starts)
@@ -2496,7 +2564,7 @@ struct EnvWaveT {
         tree_accumulate(LO(P), 10);
         if (factor_pair_ok()) {
           factor_both(m.dt);
-          invert_both(pair_base(), pair_dinv(), fac2());
+          invert_both(fac2());
         }
       } else if (m.dbg_stage == 16) {  // euler()'s second-factor route: reload, apply
         const vreal* g2 = fac2();
@@ -2522,9 +2590,9 @@ struct EnvWaveT {
       VNL_PROF(5);
       VNL_PROF(6);
       fresh().factor_both(m.dt);
-      fresh().mass_mul_pair(LO(qacc), LO(mv), pair_base(), pair_dinv());  // M * qacc_warmstart, needs L (before it becomes L^-1)
+      fresh().mass_mul_factor(LO(qacc), LO(mv));  // M * qacc_warmstart, needs L1 (before N1 takes its place)
       VNL_PROF(10);
-      fresh().invert_both(pair_base(), pair_dinv(), fac2());
+      fresh().invert_both(fac2());
     } else {
       fresh().mass_matrix(vreal(0.));
       fresh().factor();
