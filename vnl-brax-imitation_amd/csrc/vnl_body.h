@@ -54,7 +54,7 @@
 // hundred joins of a substep), only that the compiler keeps the accesses in order: the wavefront-scope fence, no instruction.
 #define VNL_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 // .. and the join behind GLOBAL memory that one lane wrote and another lane will read (xpos / xquat in the state buffers:
-// kinematics -> make_constraint and the env glue; the second factor's scratch: invert_pair -> euler): the vector-memory
+// kinematics -> make_constraint and the env glue; the second factor's scratch: invert_aba -> euler): the vector-memory
 // counter is drained, so the stores have reached the cache the loads are served from
 #define VNL_SYNC_GLOBAL()                                     \
   do {                                                        \
@@ -291,7 +291,7 @@ struct EnvWaveT {
   VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * MI(nbody); }
   VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * MI(nbody); }
   VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * MI(nv); }
-  // library-owned global scratch of this env: the second factor of a substep (factor_pair), nM + nv elements
+  // library-owned global scratch of this env: the second inverse factor of a substep (invert_aba) and its reciprocal pivots (factor_aba), nM + nv elements
   VNL_HD vreal* fac2() const { return ev.fac2 + (size_t)e * (MI(nM) + MI(nv)); }
   VNL_HD V3 gpos3(int b) const {
     const vreal* x = gxpos() + 3 * b;
@@ -981,292 +981,6 @@ struct EnvWaveT {
     }
   }
 
-  // The TWO factorisations of a substep in ONE pass: forward.euler's implicit damping needs M + h diag(damping), the
-  // solver needs M, both from the same qpos.  Their rows sit side by side in registers and go through the same
-  // scheduled elimination (one dependent chain of LDS round trips instead of two, the second system's updates fill the
-  // first one's waits); the mass matrix is built once.  System 1 ends in LO(LD) / LO(dinv) as factor_rows leaves it;
-  // system 2 (unit-lower rows scaled by 1/D, then 1/D) goes to this env's global scratch `g2` [nM + nv] and is
-  // brought back by euler() once the solver has released the pool.
-  // Which published pivots row a must absorb in which step is static per model: m.fac_match[a][step] (one bit per
-  // scratch line, host-made), read one step ahead -- no line headers, no per-step ancestor tests.
-  template <int NSET, int MAXD, int MAXD1 = MAXD>
-  VNL_HD void factor_pair(vreal h) const {
-    static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
-    constexpr int CH = MAXD % 12 == 0 ? 12 : 16;
-    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
-    constexpr int LW = MAXD + 4;  // [row numerators (MAXD) | 1/pivot | pad]
-    vreal r1[NSET][MAXD], r2[NSET][MAXD], d1[NSET], d2[NSET], inv1[NSET], inv2[NSET];
-    int dep[NSET], ftime[NSET], myline[NSET];
-    const unsigned char* mt[NSET];
-    const int sc = (LO(Ma) + 3) & ~3, sc2 = sc + VNL_FAC_LINES * LW;  // Ma .. tmp2 are dead while factorising
-    const int nsteps = MI(fac_steps);
-#pragma unroll
-    for (int q = 0; q < NSET; q++) {
-      int a = (int)lane + q * VNL_LANES;
-      bool ok = a < MI(nv);
-      int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
-      dep[q] = d;
-      d1[q] = ok ? s[LO(LD) + adr] : vreal(1.);
-      d2[q] = ok ? d1[q] + h * m.dof_damping[a] : vreal(1.);
-      inv1[q] = inv2[q] = vreal(0.);
-#pragma unroll
-      for (int c = 0; c < MAXD; c++)
-        if (c < qd(q)) r1[q][c] = r2[q][c] = c < d ? s[LO(LD) + adr + d - c] : vreal(0.);
-      myline[q] = ok ? (m.dof_fslot[a] & 0xff) : 0;
-      ftime[q] = ok ? m.dof_ftime[a] : -1;
-      mt[q] = m.fac_match + (size_t)(ok ? a : 0) * nsteps;
-    }
-    unsigned nxt[NSET];
-#pragma unroll
-    for (int q = 0; q < NSET; q++) nxt[q] = ((int)lane + q * VNL_LANES < MI(nv) && nsteps > 0) ? mt[q][0] : 0u;
-    VNL_SYNC();
-    VNL_PROF(7);
-    for (int step = 0; step < nsteps; step++) {
-      unsigned cur[NSET];
-#pragma unroll
-      for (int q = 0; q < NSET; q++) {
-        cur[q] = nxt[q];
-        nxt[q] = ((int)lane + q * VNL_LANES < MI(nv) && step + 1 < nsteps) ? mt[q][step + 1] : 0u;  // prefetch
-        if (ftime[q] == step) {
-          const int l1 = sc + myline[q] * LW, l2 = sc2 + myline[q] * LW, a = (int)lane + q * VNL_LANES;
-#pragma unroll
-          for (int c0 = 0; c0 < MAXD; c0 += CH) {
-            if (c0 < qd(q) && c0 < dep[q]) {
-#pragma unroll
-              for (int c = c0; c < c0 + CH; c += 4)
-                if (c < qd(q)) {
-                  st4a(s + l1 + c, r1[q][c], r1[q][c + 1], r1[q][c + 2], r1[q][c + 3]);
-                  st4a(s + l2 + c, r2[q][c], r2[q][c + 1], r2[q][c + 2], r2[q][c + 3]);
-                }
-            }
-          }
-          const vreal i1 = vnl_recip(d1[q]), i2 = vnl_recip(d2[q]);
-          s[l1 + MAXD] = i1, s[l2 + MAXD] = i2;
-          inv1[q] = i1, inv2[q] = i2;
-        }
-      }
-      VNL_WAVE_FENCE();
-      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
-        bool more = false;
-#pragma unroll
-        for (int q = 0; q < NSET; q++) more = more || cur[q] != 0u;
-        if (!vnl_wave_any(more)) break;
-#pragma unroll
-        for (int q = 0; q < NSET; q++) {
-          if (cur[q] != 0u) {
-            const int k = __builtin_ctz(cur[q]);
-            cur[q] &= cur[q] - 1u;
-            const vreal* ln1 = s + sc + k * LW;
-            const vreal* ln2 = s + sc2 + k * LW;
-            // first column chunk fetched together with the pivot entries and 1/D: one LDS round trip, not two
-            // (entries past the row's depth are don't-cares: never published, never stored); unconditional reads of
-            // every chunk were measured slower (2.52 vs 2.44 ms)
-            R4 x1[CH / 4], x2[CH / 4];
-#pragma unroll
-            for (int c = 0; c < CH; c += 4) x1[c / 4] = ld4a(ln1 + c), x2[c / 4] = ld4a(ln2 + c);
-            const vreal raw1 = ln1[dep[q]], raw2 = ln2[dep[q]];
-            const vreal t1 = raw1 * ln1[MAXD], t2 = raw2 * ln2[MAXD];
-#pragma unroll
-            for (int c = 0; c < CH; c += 4) {
-              R4 x = x1[c / 4], y = x2[c / 4];
-              r1[q][c] -= t1 * x.x, r1[q][c + 1] -= t1 * x.y, r1[q][c + 2] -= t1 * x.z, r1[q][c + 3] -= t1 * x.w;
-              r2[q][c] -= t2 * y.x, r2[q][c + 1] -= t2 * y.y, r2[q][c + 2] -= t2 * y.z, r2[q][c + 3] -= t2 * y.w;
-            }
-#pragma unroll
-            for (int c0 = CH; c0 < MAXD; c0 += CH) {
-              if (c0 < qd(q) && c0 < dep[q]) {
-#pragma unroll
-                for (int c = c0; c < c0 + CH; c += 4) {
-                  if (c < qd(q)) {
-                    R4 x = ld4a(ln1 + c), y = ld4a(ln2 + c);
-                    r1[q][c] -= t1 * x.x, r1[q][c + 1] -= t1 * x.y, r1[q][c + 2] -= t1 * x.z, r1[q][c + 3] -= t1 * x.w;
-                    r2[q][c] -= t2 * y.x, r2[q][c + 1] -= t2 * y.y, r2[q][c + 2] -= t2 * y.z, r2[q][c + 3] -= t2 * y.w;
-                  }
-                }
-              }
-            }
-            d1[q] -= t1 * raw1, d2[q] -= t2 * raw2;
-          }
-        }
-      }
-      VNL_WAVE_FENCE();
-    }
-    VNL_SYNC();
-    VNL_PROF(8);
-#pragma unroll
-    for (int q = 0; q < NSET; q++) {
-      int a = (int)lane + q * VNL_LANES;
-      if (a < MI(nv)) {  // the interleaved image mass_mul_pair / invert_pair read (see the packed form below)
-        const int adr = madr(a), d = dep[q], R2 = pair_base(), DV = pair_dinv();
-        s[R2 + 2 * adr] = d1[q], s[R2 + 2 * adr + 1] = d2[q];
-        s[DV + 2 * a] = inv1[q], s[DV + 2 * a + 1] = inv2[q];
-#pragma unroll
-        for (int c = 0; c < MAXD; c++)
-          if (c < qd(q) && c < d) s[R2 + 2 * (adr + d - c)] = r1[q][c] * inv1[q], s[R2 + 2 * (adr + d - c) + 1] = r2[q][c] * inv2[q];
-      }
-    }
-    VNL_SYNC();
-    VNL_PROF(9);
-  }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VNL_FAC_UNPACKED)
-#define VNL_FAC_PACKED 1
-  // factor_pair, device form (same arithmetic per row, entry by entry: the two forms agree bit for bit -- tests/test_gpu_spill.py
-  // runs the -DVNL_FAC_UNPACKED build beside the product build):
-  //  * the two systems' rows are INTERLEAVED, (M, M + h diag(damping)) pairs in even/odd registers and in the scratch
-  //    lines, so every row update is one v_pk_fma_f32 for both systems (a wave alone issues a packed FMA in the time of a
-  //    plain one: tools/microbench/issue_rate.hip) and one ds_read_b128 brings two columns of both;
-  //  * no second lane set: a row 64.. (the rodent has nine, depth <= 13) rides as a GUEST in the registers of a lane whose own
-  //    row is shallow (host table m.fac_guest: host depth <= 12, guest depth <= 24), in column chunks 1-2, which the deep
-  //    rows of other lanes occupy anyway -- the guest's updates share those lanes' instructions, each lane reading ITS
-  //    pivot line with ITS multiplier.
-  template <int MAXD, bool GUESTS>
-  VNL_HD void factor_pair_packed(vreal h) const {
-    static_assert(MAXD % 12 == 0 || MAXD == 16, "columns are processed in chunks of 12 (or 16)");
-    constexpr int CH = MAXD % 12 == 0 ? 12 : 16, NCH = MAXD / CH;
-    static_assert(!GUESTS || NCH == 3, "guest rows sit in chunks 1-2 of 3");
-    constexpr int LW = 2 * MAXD + 4;  // [(r1, r2) x MAXD | 1/pivot1, 1/pivot2 | pad]
-    v2r rr[MAXD];
-    const int sc = (LO(Ma) + 3) & ~3;  // Ma .. tmp2 are dead while factorising
-    const int nsteps = MI(fac_steps);
-    // row A = this lane's own row; row B = its guest (or none)
-    const int a = (int)lane, g = GUESTS ? m.fac_guest[lane] : -1;
-    const bool okA = a < MI(nv), hasB = g >= 0;
-    const int adrA = okA ? madr(a) : 0, depA = okA ? eadr(a) - adrA : 0;
-    const int adrB = hasB ? madr(g) : 0, depB = hasB ? eadr(g) - adrB : 0;
-    v2r dgA, dgB, ivA, ivB;  // diagonals of both systems; iv = their reciprocals once the row was a pivot
-    {
-      const vreal d1 = okA ? s[LO(LD) + adrA] : vreal(1.);
-      dgA = v2r{d1, okA ? d1 + h * m.dof_damping[a] : vreal(1.)};
-      const vreal e1 = hasB ? s[LO(LD) + adrB] : vreal(1.);
-      dgB = v2r{e1, hasB ? e1 + h * m.dof_damping[hasB ? g : 0] : vreal(1.)};
-      ivA = ivB = v2r{vreal(0.), vreal(0.)};
-    }
-#pragma unroll
-    for (int c = 0; c < MAXD; c++) {
-      vreal x = c < depA ? s[LO(LD) + adrA + depA - c] : vreal(0.);
-      if (GUESTS && c >= CH && hasB) x = c - CH < depB ? s[LO(LD) + adrB + depB - (c - CH)] : vreal(0.);
-      rr[c] = v2r{x, x};
-    }
-    const int lineA = okA ? (m.dof_fslot[a] & 0xff) : 0, lineB = hasB ? (m.dof_fslot[g] & 0xff) : 0;
-    const int ftA = okA ? m.dof_ftime[a] : -1, ftB = hasB ? m.dof_ftime[g] : -1;
-    const unsigned char* mtA = m.fac_match + (size_t)(okA ? a : 0) * nsteps;
-    const unsigned char* mtB = m.fac_match + (size_t)(hasB ? g : 0) * nsteps;
-    unsigned nxtA = (okA && nsteps > 0) ? mtA[0] : 0u, nxtB = (hasB && nsteps > 0) ? mtB[0] : 0u;
-    VNL_SYNC();
-    VNL_PROF(7);
-    for (int step = 0; step < nsteps; step++) {
-      unsigned curA = nxtA, curB = nxtB;
-      nxtA = (okA && step + 1 < nsteps) ? mtA[step + 1] : 0u;  // prefetch
-      if (GUESTS) nxtB = (hasB && step + 1 < nsteps) ? mtB[step + 1] : 0u;
-      // ---- publish the rows that are pivots in this step: register chunk k -> line columns [CH k, CH k + CH) of the own row,
-      // a guest's chunks 1-2 -> columns [0, 2 CH) of ITS line
-      const bool pubA = ftA == step, pubB = GUESTS && ftB == step;
-      if (vnl_wave_any(pubA || pubB)) {
-        const int lA = sc + lineA * LW, lB = sc + lineB * LW;
-#pragma unroll
-        for (int k = 0; k < NCH; k++) {
-          const bool guest_chunk = GUESTS && k > 0 && hasB;
-          const bool on = guest_chunk ? (pubB && depB > CH * (k - 1)) : (pubA && depA > CH * k);
-          if (on) {
-            vreal* dst = s + (guest_chunk ? lB + 2 * CH * (k - 1) : lA + 2 * CH * k);
-#pragma unroll
-            for (int c = 0; c < CH; c += 2)
-              st4a(dst + 2 * c, rr[CH * k + c][0], rr[CH * k + c][1], rr[CH * k + c + 1][0], rr[CH * k + c + 1][1]);
-          }
-        }
-        if (pubA) {
-          ivA = v2r{vnl_recip(dgA[0]), vnl_recip(dgA[1])};
-          s[lA + 2 * MAXD] = ivA[0], s[lA + 2 * MAXD + 1] = ivA[1];
-        }
-        if (pubB) {
-          ivB = v2r{vnl_recip(dgB[0]), vnl_recip(dgB[1])};
-          s[lB + 2 * MAXD] = ivB[0], s[lB + 2 * MAXD + 1] = ivB[1];
-        }
-      }
-      VNL_WAVE_FENCE();
-      // ---- absorb: row[c] -= (pivot[col of this row] / D) * pivot[c], both systems at once
-      // (measured: issuing every LDS read of a pass before its first multiply-add -- 48 more registers -- was 3 % SLOWER
-      // than this chunk-by-chunk form, 2.36 vs 2.29 ms per launch)
-      for (int pass = 0; pass < VNL_FAC_LINES; pass++) {
-        if (!vnl_wave_any((curA | curB) != 0u)) break;
-        const bool onA = curA != 0u, onB = GUESTS && curB != 0u;
-        const int kA = onA ? __builtin_ctz(curA) : 0, kB = onB ? __builtin_ctz(curB) : 0;
-        curA &= curA - 1u, curB &= curB - 1u;
-        const vreal* lnA = s + sc + kA * LW;
-        // chunk 0 belongs to row A in every lane: fetched together with the pivot entry and 1/D (one LDS round trip)
-        R4 x0[CH / 2];
-        v2r tA = v2r{vreal(0.), vreal(0.)}, rawA = tA;
-        if (onA) {
-#pragma unroll
-          for (int c = 0; c < CH; c += 2) x0[c / 2] = ld4a(lnA + 2 * c);
-          rawA = v2r{lnA[2 * depA], lnA[2 * depA + 1]};
-          tA = rawA * v2r{lnA[2 * MAXD], lnA[2 * MAXD + 1]};
-#pragma unroll
-          for (int c = 0; c < CH; c += 2) {
-            rr[c] -= tA * v2r{x0[c / 2].x, x0[c / 2].y};
-            rr[c + 1] -= tA * v2r{x0[c / 2].z, x0[c / 2].w};
-          }
-          dgA -= tA * rawA;
-        }
-        if constexpr (NCH > 1) {
-          // chunks 1 .. : row A's deeper columns, or the guest's columns [0, 2 CH) -- its own line, its own multiplier
-          v2r tB = tA;
-          const vreal* lnB = lnA;
-          bool on1 = onA && depA > CH, on2 = onA && depA > 2 * CH;
-          if (GUESTS && vnl_wave_any(hasB && onB)) {
-            const vreal* lg = s + sc + kB * LW;
-            if (hasB && onB) {
-              const v2r rawB = v2r{lg[2 * depB], lg[2 * depB + 1]};
-              tB = rawB * v2r{lg[2 * MAXD], lg[2 * MAXD + 1]};
-              dgB -= tB * rawB;
-              lnB = lg - 2 * CH;  // register column CH + c holds the guest's column c
-            }
-            if (hasB) on1 = onB, on2 = onB && depB > CH;
-          }
-#pragma unroll
-          for (int k = 1; k < NCH; k++) {
-            if (k == 1 ? on1 : on2) {
-#pragma unroll
-              for (int c = CH * k; c < CH * k + CH; c += 2) {
-                const R4 x = ld4a(lnB + 2 * c);
-                rr[c] -= tB * v2r{x.x, x.y};
-                rr[c + 1] -= tB * v2r{x.z, x.w};
-              }
-            }
-          }
-        }
-      }
-      VNL_WAVE_FENCE();
-    }
-    VNL_SYNC();
-    VNL_PROF(8);
-    // both factors leave as ONE interleaved image: (L1, L2) entry pairs (unit-lower rows scaled by 1/D) from pair_base() on,
-    // the pairs of reciprocal pivots at pair_dinv() -- mass_mul_pair and invert_pair read them there
-    const int R2 = pair_base(), DV = pair_dinv();
-    if (okA) {
-      s[R2 + 2 * adrA] = dgA[0], s[R2 + 2 * adrA + 1] = dgA[1];
-      s[DV + 2 * a] = ivA[0], s[DV + 2 * a + 1] = ivA[1];
-#pragma unroll
-      for (int c = 0; c < MAXD; c++)
-        if (c < depA && !(GUESTS && hasB && c >= CH)) {
-          const v2r v = rr[c] * ivA;
-          s[R2 + 2 * (adrA + depA - c)] = v[0], s[R2 + 2 * (adrA + depA - c) + 1] = v[1];
-        }
-    }
-    if (GUESTS && hasB) {
-      s[R2 + 2 * adrB] = dgB[0], s[R2 + 2 * adrB + 1] = dgB[1];
-      s[DV + 2 * g] = ivB[0], s[DV + 2 * g + 1] = ivB[1];
-#pragma unroll
-      for (int c = CH; c < MAXD; c++)
-        if (c - CH < depB) {
-          const v2r v = rr[c] * ivB;
-          s[R2 + 2 * (adrB + depB - (c - CH))] = v[0], s[R2 + 2 * (adrB + depB - (c - CH)) + 1] = v[1];
-        }
-    }
-    VNL_SYNC();
-    VNL_PROF(9);
-  }
-#endif
   // The two factorisations WITHOUT the matrix: the articulated-body form of L'DL.  With every spatial quantity expressed
   // about one common origin (as they are here) the elimination of dof k from the joint-space matrix is a rank-one downdate
   // of the articulated inertia of k's subtree, IA <- IA - U_k U_k' / D_k with U_k = IA cdof_k, D_k = cdof_k . U_k + armature_k
@@ -1474,7 +1188,7 @@ struct EnvWaveT {
   VNL_HD void invert_factor() const { invert_factor(LO(LD)); }
 
   // sum_{t=1..dep} LD[adr+t] * in[anc_of(adr+t)], four independent index->value chains per trip
-  // (ST: element stride of the factor -- 1, or 2 for system 1 of the interleaved pair that factor_pair leaves)
+  // (ST: element stride of the factor)
   template <int ST = 1>
   VNL_HD vreal row_dot(int adr, int dep, int in, int LDb) const {
     const unsigned char* an = (const unsigned char*)(s + LO(tab_anc)) + adr;
@@ -1682,86 +1396,6 @@ struct EnvWaveT {
     col_apply(LO(tmp2), out, 0, LO(LD), LO(dinv));
   }
 
-  // out = M v from system 1 of the INTERLEAVED pair factor_pair leaves: (L1, L2) entry pairs at R2 + 2 k, (1/D1, 1/D2) at DV + 2 a
-  VNL_HD void mass_mul_pair(int vec, int out, int R2, int DV) const {
-    if (blk_on()) {
-      blk_apply<2, false>(vec, LO(tmp2), 2, R2, DV);
-      blk_apply<2, true>(LO(tmp2), out, 0, R2, DV);
-      return;
-    }
-    VNL_FOR(i, MI(nv)) {
-      int adr = madr(i), dep = eadr(i) - adr;
-      vreal acc = s[vec + i] + row_dot<2>(adr, dep, vec, R2);
-      s[LO(tmp2) + i] = acc / s[DV + 2 * i];
-    }
-    VNL_SYNC();
-    col_apply<2>(LO(tmp2), out, 0, R2, DV);
-  }
-
-  // BOTH factors of a substep inverted in ONE pass (same recursion as invert_rows, the two systems side by side: one packed
-  // multiply-add and one 8-byte LDS read per entry pair instead of two inversions -- the second one used to run in euler()).
-  // In: the interleaved pair at R2 / DV.  Out: N1 = L1^-1 in LO(LD) and 1/D1 in LO(dinv), as every M^-1 product expects them;
-  // N2 and 1/D2 in the env's global scratch g2 [nM + nv], which euler() brings back once the solver has released the pool.
-  // All reads come before the one barrier, all writes after it (the outputs overlap the interleaved input).
-  template <int NSET, int MAXD, int MAXD1 = MAXD>
-  VNL_HD void invert_pair(int R2, int DV, vreal* g2) const {
-    auto qd = [](int q) constexpr { return (NSET == 2 && q == 1) ? MAXD1 : MAXD; };
-    v2r nn[NSET][MAXD], dg[NSET];
-    int adrs[NSET], deps[NSET];
-#pragma unroll
-    for (int q = 0; q < NSET; q++) {
-      const int a = (int)lane + q * VNL_LANES;
-      const bool ok = a < MI(nv);
-      const int adr = ok ? madr(a) : 0, d = ok ? eadr(a) - adr : 0;
-      adrs[q] = adr, deps[q] = d;
-      const vreal* own = s + R2 + 2 * adr;
-      dg[q] = v2r{own[0], own[1]};
-      const vreal* pb[MAXD];  // pair row of the u-th ancestor (rows past the depth alias row 0: read, never used)
-#pragma unroll
-      for (int u = 1; u < MAXD; u++)
-        if (u < qd(q)) pb[u] = s + R2 + 2 * (u < d ? madr(anc_of(adr + u)) : 0);
-#pragma unroll
-      for (int t = 1; t < MAXD; t++) {
-        if (t < qd(q) && vnl_wave_any(t <= d)) {
-          // the operands of entry t are fetched XB pairs at a time before their (dependent) multiply-add chain: all of
-          // them at once (invert_rows) would need 2 x 35 registers here
-          constexpr int XB = 8;
-          v2r acc = t <= d ? v2r{-own[2 * t], -own[2 * t + 1]} : v2r{vreal(0.), vreal(0.)};
-#pragma unroll
-          for (int u0 = 1; u0 < t; u0 += XB) {
-            v2r x[XB];
-#pragma unroll
-            for (int u = u0; u < u0 + XB; u++)
-              if (u < t) x[u - u0] = v2r{pb[u][2 * (t - u)], pb[u][2 * (t - u) + 1]};
-#pragma unroll
-            for (int u = u0; u < u0 + XB; u++)
-              if (u < t) acc -= nn[q][u] * x[u - u0];
-          }
-          nn[q][t] = acc;
-        }
-      }
-    }
-    v2r dv[NSET];
-#pragma unroll
-    for (int q = 0; q < NSET; q++) {
-      const int a = (int)lane + q * VNL_LANES;
-      dv[q] = a < MI(nv) ? v2r{s[DV + 2 * a], s[DV + 2 * a + 1]} : v2r{vreal(0.), vreal(0.)};
-    }
-    VNL_SYNC();
-#pragma unroll
-    for (int q = 0; q < NSET; q++) {
-      const int a = (int)lane + q * VNL_LANES;
-      if (a < MI(nv)) {
-        const int adr = adrs[q], d = deps[q];
-        s[LO(LD) + adr] = dg[q][0], g2[adr] = dg[q][1];
-        s[LO(dinv) + a] = dv[q][0], g2[MI(nM) + a] = dv[q][1];
-#pragma unroll
-        for (int t = 1; t < MAXD; t++)
-          if (t < qd(q) && t <= d) s[LO(LD) + adr + t] = nn[q][t][0], g2[adr + t] = nn[q][t][1];
-      }
-    }
-    VNL_SYNC();
-  }
   VNL_HD void invert_both(vreal* g2) const {
     if (MI(nv) <= VNL_ROWSETS_1 * VNL_LANES) invert_aba<VNL_ROWSETS_1, false>(g2);
 #if VNL_LANES == 64
@@ -1769,10 +1403,6 @@ struct EnvWaveT {
 #endif
     else invert_aba<VNL_ROWSETS_2, false>(g2);
   }
-  // where factor_pair leaves the interleaved pair: from LO(LD) on (through LO(dinv) into the pool, below cvel), and the pair of
-  // reciprocal pivots in the first two of the eight CG vectors (dead until the solver starts)
-  VNL_HD int pair_base() const { return LO(LD); }
-  VNL_HD int pair_dinv() const { return LO(Ma); }
 
   // ------------------------------------------------------------------ velocity
   // com_vel + rne: -qfrc_bias - damping*qvel -> LO(smooth).  Body velocities / accelerations are tree prefixes
@@ -2650,11 +2280,11 @@ struct EnvWaveT {
     VNL_FOR(d, nv) s[LO(tmp) + d] = MI(eulerdamp) ? s[LO(smooth) + d] + s[LO(qfrc_c) + d] : s[LO(qacc) + d];
     VNL_SYNC();
     if (MI(eulerdamp) && factor_pair_ok()) {
-      // the INVERTED factor of M + h diag(damping) was made beside M's by forward() (factor_pair + invert_pair): bring it
+      // the INVERTED factor of M + h diag(damping) was made beside M's by forward() (factor_aba + invert_aba): bring it
       // into the pool (the constraint rows are dead now) and apply it
       const vreal* g2 = fac2();
       const int n2 = MI(nM) + MI(nv);
-      VNL_SYNC_GLOBAL();  // (written by invert_pair, one row per lane; read here element by element)
+      VNL_SYNC_GLOBAL();  // (written by invert_aba, one row per lane; read here element by element)
       VNL_FOR(k, n2) s[LO(P) + k] = g2[k];
       VNL_SYNC();
       fresh().solve_inplace(LO(tmp), LO(P), LO(P) + MI(nM));

@@ -418,7 +418,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
       d.fac_nleaf |= deep1 << 8;
     }
     UPI(dof_ftime, ftime) UPI(dof_fslot, fslot)
-    {  // guests of factor_pair_packed: rows 64.. placed into lanes whose own row is shallow (deepest guests first)
+    {  // guests of invert_aba: rows 64.. placed with lanes whose own row is shallow (deepest guests first), so that own + guest <= 36 entries
       d.fac_guest = nullptr;
       if (nv > 64 && nv <= 128) {
         std::vector<int> guest(64, -1), order;
@@ -435,7 +435,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         if (ok) UPI(fac_guest, guest)
       }
     }
-    {  // fac_match[a][t]: the scratch lines whose pivot of step t lies strictly below row a (factor_pair absorbs them)
+    {  // fac_match[a][t]: the scratch lines whose pivot of step t lies strictly below row a (factor_aba absorbs them)
       const int nst = d.fac_steps;
       std::vector<unsigned char> match((size_t)nv * (nst > 0 ? nst : 1), 0);
       for (int j = 0; j < nv; j++)

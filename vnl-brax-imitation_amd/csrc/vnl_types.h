@@ -62,7 +62,7 @@ struct DevModel {
   const int *dof_body, *dof_Madr, *dof_depth, *dof_limrow;
   const int *M_anc, *M_row;          /* per entry: column dof / row dof */
   const int *dof_ftime, *dof_fslot;  /* factorisation schedule: step in which row a is the pivot; scratch line | one leaf under a << 8 | mask of all leaves under a << 16 */
-  const int* fac_guest;              /* [64] row 64.. that rides in lane l's registers during factor_pair_packed (-1: none); null if
+  const int* fac_guest;              /* [64] row 64.. that lane l inverts after its own row (EnvWave::invert_aba; -1: none); null if
                                         the model has no such rows or they cannot be placed (host depth <= 12, guest depth <= 24) */
   const unsigned* blk_tab;           /* [trips_row x 64 | trips_col x 64] block descriptors of blk_apply (vnl_lib.hip builds them); null if blk_cfg == 0 */
   const unsigned char* fac_match;    /* [nv][fac_steps]: bit k set = row a absorbs the pivot published in scratch line k in that step */
@@ -87,7 +87,7 @@ struct DevEnv {
   const int *body_idxs, *end_eff_idx, *app_body, *app_ref_col, *joint_cols;
   const float *position, *quaternion, *joints, *body_positions, *velocity, *angular_velocity, *joints_velocity;
   const float* center_of_mass; /* (C,T,3) or null: reference for rcom (else body_positions[com_ref_col]) */
-  vreal* fac2; /* library-owned scratch [num_envs][nM + nv]: the second factor of a substep (EnvWave::factor_pair) */
+  vreal* fac2; /* library-owned scratch [num_envs][nM + nv]: the second inverse factor of a substep (EnvWave::invert_aba) */
 };
 
 // caller-owned buffers, row-major [env][feature] (see include/vnl.h vnl_state)
@@ -112,7 +112,7 @@ struct WsLayout {
   int con_r, con_t1;    /* 3 per contact / 3 per collidable geom */
   int tab_anc, tab_madr, tab_body, tab_jump, tab_lvl; /* 8/16-bit index tables staged in LDS */
   int act_list;         /* ncon bytes: contacts with D != 0, then their count (int) */
-  int pair_room;        /* elements from LD to the part of the pool that stays live across the factorisation (cvel): room of the interleaved factor pair */
+  int pair_room;        /* elements from LD to the part of the pool that stays live across the factorisation (cvel): (kept for the layout's stability; the articulated-body factorisation needs 12 nv elements of the pool below cvel) */
   int newt_M, newt_H, newt_J; /* Newton solver only: dense qM (nv^2), Hessian / its Cholesky factor (nv^2), dense efc_J (nefc x nv) */
   int total;
 };
