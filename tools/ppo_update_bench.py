@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--torch", action="store_true", help="time the autograd path instead (hipBLASLt)")
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile of the hand-written path (64 / 128)")
     ap.add_argument("--wg-target", type=int, default=0, help="workgroups a split-K weight gradient is split up to (default 256)")
+    ap.add_argument("--fused", action="store_true", help="the intention network's forward as ONE launch (csrc/vnl_policy.hip, training form) instead of layer by layer")
+    ap.add_argument("--noprio", action="store_true", help="no raised wave priority for the intention network's GEMMs")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses, running_statistics
     from vnl_brax_imitation_amd.ppo_imitation.intention_policy_network import LeafParams
@@ -49,6 +51,10 @@ def main():
         upd = hip_update.HipPPOUpdate(nets, cfg["T"], cfg["B"], dev, **HP)
         if a.tile or a.wg_target:
             assert upd.lib.vnl_ppo_update_tune(upd.h, a.tile, a.wg_target) == 0
+        if a.fused:
+            assert upd.lib.vnl_ppo_update_tune(upd.h, -1, 0) == 0
+        if a.noprio:
+            assert upd.lib.vnl_ppo_update_tune(upd.h, -2, 0) == 0
 
         def step():
             upd.grad(flat, ndev, data, noise, grads)

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["vnl_lib.hip", "vnl_policy.hip", "vnl_ppo.hip"]
-DEPS = SOURCES + ["vnl_body.h", "vnl_types.h", "../../include/vnl.h"]
+DEPS = SOURCES + ["vnl_body.h", "vnl_types.h", "vnl_policy_train.h", "../../include/vnl.h"]
 OUT = os.path.join(HERE, "libvnl.so")
 
 # Diagnostic / regression builds of the SAME sources (never the product library, only loaded by tools/ and tests/):
@@ -59,16 +59,47 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, kno
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-Rpass-analysis=kernel-resource-usage", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize",
-           "-std=c++17", "-shared", "-fPIC", "-o", out] + defs + os.environ.get("VNL_HIPCC_EXTRA", "").split() + \
-          [os.path.join(HERE, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+    # One object per source, kept under _obj/<variant>/ with the compiler's resource-usage remarks beside it: a change to the
+    # PPO or policy kernels does not recompile the env kernels (two minutes), and the register-budget check below still sees
+    # every kernel's remarks.
+    objdir = os.path.join(HERE, "_obj", variant)
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["-Rpass-analysis=kernel-resource-usage", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC"] + \
+        defs + os.environ.get("VNL_HIPCC_EXTRA", "").split()
+    stamp = " ".join(flags)
+    headers = [d for d in deps if not d.endswith(".hip")]
+    SRC_DEPS = {"vnl_lib.hip": headers, "vnl_policy.hip": [h for h in headers if h.endswith("vnl.h")] + [os.path.join(HERE, "vnl_policy_train.h")],
+                "vnl_ppo.hip": [h for h in headers if h.endswith("vnl.h")] + [os.path.join(HERE, "vnl_policy_train.h")]}
+    objs, remarks = [], ""
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        rem = obj + ".remarks.txt"
+        srcdeps = [os.path.join(HERE, src)] + [h for h in SRC_DEPS.get(src, headers) if os.path.exists(h)]
+        fresh = (not force and os.path.exists(obj) and os.path.exists(rem) and
+                 os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in srcdeps) and
+                 open(rem).readline().rstrip("\n") == stamp)
+        if not fresh:
+            cmd = [hipcc] + flags + ["-c", os.path.join(HERE, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            if verbose or r.returncode:
+                sys.stderr.write(r.stderr)
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(rem, "w") as f:
+                f.write(stamp + "\n" + r.stderr)
+        objs.append(obj)
+        remarks += open(rem).read().split("\n", 1)[1]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-    if verbose or r.returncode:
-        sys.stderr.write(r.stderr)
     if r.returncode:
+        sys.stderr.write(r.stderr)
         raise subprocess.CalledProcessError(r.returncode, cmd)
+
+    class _R:  # (the check below reads the remarks of all objects, cached or not)
+        stderr = remarks
+    r = _R()
     # Register budget of the env kernels: a PERFORMANCE check (two waves per SIMD and no private-memory stack are what
     # the measured numbers assume), not a correctness one -- the spill variant runs the parity tests with 212 bytes of
     # scratch per lane.  Fails closed: if the compiler's remarks for the env kernels are not found, the build is

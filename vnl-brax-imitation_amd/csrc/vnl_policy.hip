@@ -22,6 +22,7 @@
 #include <stdio.h>
 
 #include "../../include/vnl.h"
+#include "vnl_policy_train.h"
 
 #define PT 16          /* envs per workgroup = rows of the 16x16x4 MFMA tile */
 #define PTHREADS 1024  /* 16 waves: four per SIMD, some compute while the others wait for their weight loads */
@@ -29,16 +30,6 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct PolicyDev {
-  int traj_size, obs_size, act_size, latent;
-  int n_enc, n_dec;
-  int enc[8], dec[8];
-  // parameter offsets (floats) inside the flat buffer
-  int enc_w[8], enc_b[8], enc_g[8], enc_be[8];
-  int mean_w, mean_b, lv_w, lv_b;
-  int dec_w[8], dec_b[8], dec_g[8], dec_be[8];
-  int ldA, ldB;  // leading dimensions (= 2 mod 32: the A-fragment ds_read_b32 is conflict-free) of the two LDS activation buffers
-};
 
 // Y[16 x N] (LDS, ld = ldy) = X[16 x K] (LDS, ld = ldx) @ W[K x N] (global, row-major) + b, optional ReLU.
 //
@@ -173,9 +164,20 @@ __device__ __forceinline__ void dense_tile(const float* X, int ldx, int K, const
     dense_tile_t<false>(X, ldx, K, params, w_off, b_off, N, Y, ldy, relu, P, split, w2_off, b2_off);
 }
 
-// in-place LayerNorm over the N columns of each of the PT rows (one row per wave)
+// the tile's rows (LDS, ld) -> dst[(e0 + r) * width + c], r < nrow: what the training form leaves for the backward pass
+__device__ __forceinline__ void store_tile(const float* src, int ld, int nrow, int width, float* __restrict__ dst, int e0) {
+  for (int i = threadIdx.x; i < nrow * width; i += PTHREADS) {
+    const int r = i / width, c = i - r * width;
+    dst[(size_t)(e0 + r) * width + c] = src[r * ld + c];
+  }
+}
+
+// in-place LayerNorm over the N columns of each of the PT rows (one row per wave); the training form computes the variance
+// in two passes (as csrc/vnl_ppo.hip's ln_fwd_kernel does) and leaves mean | 1 / sqrt(var + eps) of the rows in stats
+template <bool TRAIN>
 __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const float* __restrict__ g,
-                                                const float* __restrict__ be) {
+                                                const float* __restrict__ be, float* __restrict__ stats = nullptr, int e0 = 0,
+                                                int nrow = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPW = PT / (PTHREADS / 64);  // rows per wave
   // scale / bias of the first 256 columns are requested before the row statistics (their latency passes under them)
@@ -195,7 +197,17 @@ __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const 
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o), ss += __shfl_xor(ss, o);
     float mean = s / (float)N;
     float var = fmaxf(ss / (float)N - mean * mean, 0.f);
+    if (TRAIN) {
+      float q = 0.f;
+      for (int c = lane; c < N; c += 64) {
+        const float d = y[c] - mean;
+        q += d * d;
+      }
+      for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      var = q / (float)N;
+    }
     float inv = rsqrtf(var + LN_EPS);
+    if (TRAIN && lane == 0 && r < nrow) stats[2 * (size_t)(e0 + r)] = mean, stats[2 * (size_t)(e0 + r) + 1] = inv;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = lane + 64 * q;
@@ -260,7 +272,8 @@ extern "C" int vnl_policy_profile_stamps(long long* out) {
 
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-__global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const float* __restrict__ params,
+template <bool TRAIN>
+__global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel_t(PolicyDev p, const float* __restrict__ params,
                                                               const float* __restrict__ obs_mean,
                                                               const float* __restrict__ obs_std,
                                                               const float* __restrict__ traj, const float* __restrict__ obs,
@@ -271,7 +284,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
                                                               float* __restrict__ logits, float* __restrict__ lat_mean,
                                                               float* __restrict__ lat_logvar,
                                                               const float* __restrict__ rand_action,
-                                                              float* __restrict__ rand_log_prob) {
+                                                              float* __restrict__ rand_log_prob, PolicyTrainOut t) {
   extern __shared__ __align__(16) float lds[];
   float* A = lds;
   float* B = lds + PT * p.ldA;
@@ -290,8 +303,13 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
   for (int l = 0; l < p.n_enc; l++) {
     dense_tile(X, ldx, K, params, p.enc_w[l], p.enc_b[l], p.enc[l], Y, ldy, true, P);
     POL_STAMP(2 + 2 * l);
-    layer_norm_rows(Y, ldy, p.enc[l], params + p.enc_g[l], params + p.enc_be[l]);
+    if (TRAIN) {
+      store_tile(Y, ldy, nrow, p.enc[l], t.encH[l], e0);
+      __syncthreads();  // (LayerNorm works in place, a wave per row)
+    }
+    layer_norm_rows<TRAIN>(Y, ldy, p.enc[l], params + p.enc_g[l], params + p.enc_be[l], t.encS[l], e0, nrow);
     __syncthreads();
+    if (TRAIN) store_tile(Y, ldy, nrow, p.enc[l], t.encY[l], e0);
     POL_STAMP(3 + 2 * l);
     float* t = X;
     X = Y, Y = t;
@@ -307,6 +325,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     dense_tile(X, ldx, K, params, p.lv_w, p.lv_b, p.latent, Y + p.latent, ldy, false, P);
   }
   POL_STAMP(10);
+  if (TRAIN) store_tile(Y, ldy, nrow, 2 * p.latent, t.ml, e0);
   // ---- z = mean + eps * exp(logvar / 2) (ipn:73-76); decoder input [z | normalised obs] -> X
   for (int i = tid; i < PT * p.latent; i += PTHREADS) {
     int r = i / p.latent, c = i - r * p.latent;
@@ -322,6 +341,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
   // normalised obs (running_statistics.normalize; traj is NOT normalised)
   load_tile(obs + (size_t)e0 * p.obs_size, nrow, p.obs_size, X + p.latent, ldx, obs_mean, obs_std);
   __syncthreads();
+  if (TRAIN) store_tile(X, ldx, nrow, p.latent + p.obs_size, t.D0, e0);
   POL_STAMP(11);
   // ---- decoder (ipn:56-70): [Dense -> ReLU -> LayerNorm] x (n-1), last Dense linear
   K = p.latent + p.obs_size;
@@ -330,8 +350,13 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     dense_tile(X, ldx, K, params, p.dec_w[l], p.dec_b[l], p.dec[l], Y, ldy, !last, P);
     POL_STAMP(12 + 2 * l);
     if (!last) {
-      layer_norm_rows(Y, ldy, p.dec[l], params + p.dec_g[l], params + p.dec_be[l]);
+      if (TRAIN) {
+        store_tile(Y, ldy, nrow, p.dec[l], t.decH[l], e0);
+        __syncthreads();
+      }
+      layer_norm_rows<TRAIN>(Y, ldy, p.dec[l], params + p.dec_g[l], params + p.dec_be[l], t.decS[l], e0, nrow);
       __syncthreads();
+      if (TRAIN) store_tile(Y, ldy, nrow, p.dec[l], t.decY[l], e0);
     }
     float* t = X;
     X = Y, Y = t;
@@ -346,6 +371,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel(PolicyDev p, const
     int r = i / (2 * na), c = i - r * 2 * na;
     if (r < nrow) logits[(size_t)(e0 + r) * 2 * na + c] = X[r * ldx + c];
   }
+  if (TRAIN) return;  // (sampling belongs to acting; the loss head works from the logits)
   float* lp = Y;  // per-(env, action) log-prob terms
   for (int i = tid; i < PT * na; i += PTHREADS) {
     int r = i / na, c = i - r * na;
@@ -490,8 +516,10 @@ extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, in
   }
   p->device = device, p->max_batch = max_batch;
   if (p->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)vnl_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)p->lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
     if (e != hipSuccess) {
       delete p;
       return pfail(VNL_ERR_HIP, hipGetErrorString(e));
@@ -518,9 +546,26 @@ extern "C" int vnl_policy_forward(vnl_policy* p, const float* params, const floa
   if ((obs_mean == nullptr) != (obs_std == nullptr)) return pfail(VNL_ERR_ARG, "obs_mean / obs_std must both be given or both null");
   if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
   int grid = (batch + PT - 1) / PT;
-  hipLaunchKernelGGL(vnl_policy_kernel, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
+  hipLaunchKernelGGL(vnl_policy_kernel_t<false>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
                      obs_mean, obs_std, traj, obs, eps_latent, eps_action, (int)batch, (int)deterministic, action,
-                     raw_action, log_prob, logits, latent_mean, latent_logvar, rand_action, rand_log_prob);
+                     raw_action, log_prob, logits, latent_mean, latent_logvar, rand_action, rand_log_prob, PolicyTrainOut{});
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pfail(VNL_ERR_HIP, hipGetErrorString(e));
+  return VNL_OK;
+}
+
+// The same kernel in its TRAINING form (csrc/vnl_ppo.hip: the intention network's forward pass of a PPO minibatch step):
+// no sampling; besides the logits and the latent heads it leaves every intermediate the backward pass reads.
+int vnl_policy_forward_train_(vnl_policy* p, const float* params, const float* obs_mean, const float* obs_std, const float* traj,
+                              const float* obs, const float* eps_latent, int32_t batch, float* logits, float* latent_mean,
+                              float* latent_logvar, const PolicyTrainOut* out, void* stream) {
+  if (!p || !params || !traj || !obs || !eps_latent || !logits || !latent_mean || !latent_logvar || !out)
+    return pfail(VNL_ERR_ARG, "vnl_policy_forward_train_: null argument");
+  if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
+  const int grid = (batch + PT - 1) / PT;
+  hipLaunchKernelGGL(vnl_policy_kernel_t<true>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
+                     obs_mean, obs_std, traj, obs, eps_latent, (const float*)nullptr, (int)batch, 1, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, logits, latent_mean, latent_logvar, (const float*)nullptr, (float*)nullptr, *out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pfail(VNL_ERR_HIP, hipGetErrorString(e));
   return VNL_OK;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/vnl.h"
+#include "vnl_policy_train.h"
 
 void vnl_set_error_(const char* msg);
 int vnl_ppo_head_phase_(const vnl_ppo_head_args* a, float* workspace, void* stream, int phase);  // vnl_lib.hip
@@ -45,6 +46,8 @@ struct GemmArgs {
   float* zout;       // EPI_SWISH: pre-activations out [M][ldc]
   float* bias_out;   // ones_row (TA only): row M-1 of the result is the column sum of B -> bias gradient [N]
   int M, N, K, lda, ldb, ldc, ldaux, k_chunk, accumulate, vecA, vecB, ones_row, direct;
+  int prio;  // s_setprio level of the launch's waves (0 .. 3): the intention network's small, latency-bound GEMMs run beside the
+             // value MLP's chip-filling ones and take the matrix cores first
   size_t slab_stride;  // floats between the slabs of a split-K launch (blockIdx.z)
 };
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SWISH = 2, EPI_MUL_DSWISH = 3 };
@@ -69,6 +72,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   __shared__ __align__(16) float As[2][A_FLOATS];
   __shared__ __align__(16) float Bs[2][B_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  if (g.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
   float* C = g.C + (size_t)bz * g.slab_stride;
@@ -370,12 +374,13 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
   hipStream_t st;
   SlabPool* pool;
   GemmGroup* group = nullptr;  // non-null: 64 x 64 weight gradients are collected here and launched together by flush()
+  int prio = 0;
   void flush() {
     if (group) launch_wgrad_group(st, *group);
   }
   void run(bool TA, bool TB, int epi, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
            const float* bias = nullptr, const float* aux = nullptr, int ldaux = 0, float* zout = nullptr, int accumulate = 0) {
-    GemmArgs g{A, B, C, bias, aux, zout, nullptr, M, N, K, lda, ldb, ldc, ldaux, K, accumulate, 0, 0, 0, 1, 0};
+    GemmArgs g{A, B, C, bias, aux, zout, nullptr, M, N, K, lda, ldb, ldc, ldaux, K, accumulate, 0, 0, 0, 1, prio, 0};
     g.vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
     g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -388,7 +393,7 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
   // that reduce_jobs_kernel sums at the end of the step (or written directly when one slab suffices)
   void wgrad(const float* X, int ldx, const float* dZ, int lddz, float* dW, float* db, int in, int out, int rows) {
     const int M = in + 1, N = out, K = rows;
-    GemmArgs g{X, dZ, dW, nullptr, nullptr, nullptr, db, M, N, K, ldx, lddz, N, 0, K, 0, 0, 0, 1, 1, 0};
+    GemmArgs g{X, dZ, dW, nullptr, nullptr, nullptr, db, M, N, K, ldx, lddz, N, 0, K, 0, 0, 0, 1, 1, prio, 0};
     g.vecA = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
     g.vecB = (lddz % 4 == 0) && (((uintptr_t)dZ) % 16 == 0);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
@@ -450,6 +455,7 @@ __global__ void __launch_bounds__(256) prep_kernel(const float* obs, const float
 template <int PER>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* H, const float* gamma, const float* beta, float* Y, float* stats,
                                                      int rows, int h) {
+  __builtin_amdgcn_s_setprio(3);  // (the intention network's chain of small launches runs beside chip-filling GEMMs)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float gm[PER], bt[PER];
 #pragma unroll
@@ -497,6 +503,7 @@ static void ln_fwd(hipStream_t st, const float* H, const float* gamma, const flo
 template <int HMAX, int NW>
 __global__ void __launch_bounds__(64 * NW) ln_bwd_kernel(const float* dY, const float* H, const float* stats, const float* gamma,
                                                          float* dZ, float* part, int rows, int h, int part_stride) {
+  __builtin_amdgcn_s_setprio(3);
   constexpr int PER = HMAX / 64;
   __shared__ float red[NW][2][HMAX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -585,6 +592,7 @@ __global__ void __launch_bounds__(256) value_seed_kernel(const float* gv, const 
 // z = mean + eps exp(0.5 logvar); D0 = [z | normalised obs]
 __global__ void __launch_bounds__(256) reparam_kernel(const float* ml /* [N][2 lat]: mean | logvar */, const float* eps, const float* obsn,
                                                       float* D0, int N, int lat, int no) {
+  __builtin_amdgcn_s_setprio(3);
   const int w = lat + no;
   const size_t n = (size_t)N * w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -597,6 +605,7 @@ __global__ void __launch_bounds__(256) reparam_kernel(const float* ml /* [N][2 l
 // d[mean | logvar] = through z (dD0[:, :lat]) + the KL term's own gradient
 __global__ void __launch_bounds__(256) latent_bwd_kernel(const float* dD0, int ldd, const float* ml, const float* eps, const float* gklm,
                                                          const float* gkll, float* dml, int N, int lat) {
+  __builtin_amdgcn_s_setprio(3);
   const size_t n = (size_t)N * lat;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / lat), c = (int)(i % lat);
@@ -678,6 +687,7 @@ __global__ void __launch_bounds__(VNL_CORR_THREADS) prediction_corr_kernel(const
 }
 
 __global__ void __launch_bounds__(256) split_ml_kernel(const float* ml, float* mean, float* logvar, int N, int lat) {
+  __builtin_amdgcn_s_setprio(3);
   const size_t n = (size_t)N * lat;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / lat), c = (int)(i % lat);
@@ -711,6 +721,12 @@ struct vnl_ppo_update {
   int tile = 0, wg_target = 512;  // (wg_target: workgroups a split-K weight gradient is split up to; 512 measured best)
   size_t slab_floats = 0, slab_floats_p = 0, part_floats = 0;  // (slab_floats_p: the intention network's share, at the end)
   std::vector<float*> encH, encY, encS, decH, decY, decS, valZ, valA;
+  vnl_policy* fused = nullptr;  // the intention network's forward pass as ONE launch (csrc/vnl_policy.hip in its training form);
+                                // null: the network is outside that kernel's limits -> layer by layer
+  bool layered = true;          // the layer-by-layer forward is the default: measured 0.462 ms per step against 0.496 with the fused
+                                // kernel, whose 132 KB of LDS per workgroup keeps the value MLP's GEMMs off 160 CUs while it runs
+                                // (tools/ppo_update_bench.py --fused switches it on)
+  int prio = 3;                 // wave priority of the intention network's GEMMs (tuning knob: tile = -2 switches it off)
 };
 
 static int dalloc(vnl_ppo_update* u, float** p, size_t n) {
@@ -725,6 +741,7 @@ extern "C" void vnl_ppo_update_destroy(vnl_ppo_update* u) {
   if (!u) return;
   for (void* p : u->allocs) (void)hipFree(p);
   if (u->s2) (void)hipStreamDestroy(u->s2);
+  if (u->fused) vnl_policy_destroy(u->fused);
   for (hipEvent_t e : u->ev)
     if (e) (void)hipEventDestroy(e);
   delete u;
@@ -732,6 +749,14 @@ extern "C" void vnl_ppo_update_destroy(vnl_ppo_update* u) {
 
 // tuning knob of tools/ppo_update_bench.py (not part of include/vnl.h): force the GEMM tile (64 / 128; 0 = by shape)
 extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
+  if (u && tile == -1) {  // the intention network's forward as one fused launch
+    u->layered = false;
+    return VNL_OK;
+  }
+  if (u && tile == -2) {
+    u->prio = 0;
+    return VNL_OK;
+  }
   if (!u || (tile != 0 && tile != 64 && tile != 128)) return pfail(VNL_ERR_ARG, "vnl_ppo_update_tune: tile must be 0, 64 or 128");
   u->tile = tile;
   if (wg_target > 0) u->wg_target = wg_target;
@@ -864,6 +889,17 @@ extern "C" int vnl_ppo_update_create(const vnl_ppo_net_spec* sp, int32_t T, int3
   u->part_floats = 256 * 2 * (size_t)wmax;
   AL(u->part, u->part_floats);
 #undef AL
+  if (rc == VNL_OK) {  // the fused forward of the intention network, if it fits that kernel (else layer by layer: not an error)
+    vnl_policy_spec ps{};
+    ps.traj_size = sp->traj_size, ps.obs_size = sp->obs_size, ps.action_size = sp->action_size, ps.latent_size = sp->latent_size;
+    ps.num_encoder_layers = sp->num_encoder_layers, ps.num_decoder_layers = sp->num_decoder_layers;
+    for (int i = 0; i < 8; i++) ps.encoder_layers[i] = sp->encoder_layers[i], ps.decoder_layers[i] = sp->decoder_layers[i];
+    vnl_policy* pol = nullptr;
+    if (vnl_policy_create(&ps, N, device, &pol) == VNL_OK) {
+      if ((size_t)vnl_policy_num_params(pol) == u->n_policy) u->fused = pol;
+      else vnl_policy_destroy(pol);
+    }
+  }
   (void)hipSetDevice(prev);
   if (rc != VNL_OK) {
     vnl_ppo_update_destroy(u);
@@ -947,7 +983,7 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
   pool.wg_target = poolP.wg_target = u->wg_target;
   GemmGroup group;
   group.n = 0;
-  Gemm GV{st, &pool}, GP{sp2, &poolP, &group};
+  Gemm GV{st, &pool}, GP{sp2, &poolP, &group, u->prio};
   auto reduce_pool = [](SlabPool& pl, hipStream_t s) {
     if (pl.jobs.njobs == 0) return;
     const unsigned total4 = pl.jobs.start4[pl.jobs.njobs];
@@ -991,6 +1027,19 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       const DenseP& d = u->val[nvl - 1];
       hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
     }
+    if (u->fused && !u->layered) {
+      // the whole intention network as ONE launch: a 16-row tile goes through encoder, latent heads, reparameterisation and
+      // decoder without leaving LDS (csrc/vnl_policy.hip, the acting path's kernel in its training form), writing what
+      // the backward pass reads; it takes the raw trajectory / observation, so it does not wait for prep_kernel
+      PolicyTrainOut to{};
+      for (size_t i = 0; i < u->enc.size(); i++) to.encH[i] = u->encH[i], to.encS[i] = u->encS[i], to.encY[i] = u->encY[i];
+      for (size_t i = 0; i < u->dec.size(); i++)
+        if (u->dec[i].ln) to.decH[i] = u->decH[i], to.decS[i] = u->decS[i], to.decY[i] = u->decY[i];
+      to.ml = u->ml, to.D0 = u->D0;
+      const int rc = vnl_policy_forward_train_(u->fused, P, bt->obs_mean, bt->obs_std, bt->traj, bt->obs, bt->eps_latent, N, u->logits,
+                                               u->mean, u->logvar, &to, sp2);
+      if (rc != VNL_OK) return rc;
+    } else {
     // encoder (intention_policy_network.py:20-44)
     {
       const float* x = u->trajp;
@@ -1023,6 +1072,7 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
           GP.run(false, false, EPI_NONE, x, ldx, P + d.w, d.out, u->logits, d.out, N, d.out, d.in, P + d.b);
         }
       }
+    }
     }
     PCHK(hipEventRecord(u->ev[1], sp2));
     // ---------------- loss head: GAE, clipped surrogate, value / entropy / KL terms and d loss / d (network outputs)
@@ -1124,6 +1174,9 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       GP.wgrad(xin, ldx, dzi, d.out, Gr + d.w, Gr + d.b, d.in, d.out, N);
       if (i > 0) GP.run(false, true, EPI_NONE, dzi, d.out, P + d.w, d.out, dy, d.in, N, d.in, d.out);
     }
+    // (measured and dropped: the decoder's weight gradients as a launch of their own as soon as their operands are ready --
+    // on a third stream hipGraph capture faulted in hipStreamEndCapture, on the caller's stream behind the value MLP's GEMMs
+    // the replayed graph started this chain late: 0.49 ms per step against 0.46)
     GP.flush();  // every weight gradient of the intention network: one grouped launch
     reduce_pool(poolP, sp2);
   }
