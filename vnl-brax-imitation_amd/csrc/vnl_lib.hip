@@ -1010,9 +1010,14 @@ __global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_gae_kernel(vnl_ppo_h
   const float adv_mean = vnl_block_sum(sa, red) / (float)N, r_mean = vnl_block_sum(sr, red) / (float)N;
   float qa = 0.f, qr = 0.f;
   __syncthreads();
+  const float inv_n = 1.f / (float)N;
   for (int n = tid; n < N; n += VNL_HEAD_THREADS) {
     const float da = a.advantages[n] - adv_mean, dr = a.reward[n] * a.reward_scaling - r_mean;
     qa += da * da, qr += dr * dr;
+    // d v_loss / d baseline (v_loss = 0.25 mean((vs - baseline)^2), vs under stop_gradient: intention_losses.py:137-139) needs
+    // nothing of the policy network: it is final here, so the value MLP's backward pass can start while the intention
+    // network's forward is still running (csrc/vnl_ppo.hip)
+    a.g_baseline[n] = -0.5f * (a.vs[n] - a.baseline[n]) * inv_n;
   }
   const float va = vnl_block_sum(qa, red) / (float)N, vr = vnl_block_sum(qr, red) / (float)N;
   if (tid == 0) stats[0] = adv_mean, stats[1] = sqrtf(va), stats[2] = vr;
@@ -1023,6 +1028,9 @@ __global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_head_kernel(vnl_ppo_
   __shared__ float red[VNL_HEAD_THREADS];
 #else
   float red[1];
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);  // (in a PPO step this launch sits on the intention network's chain, beside the value MLP's GEMMs)
 #endif
   const int tid = (int)threadIdx.x, A = a.act, N = a.T * a.B;
   const int lane = tid % VNL_HEAD_GROUP, group = (int)(blockIdx.x * (VNL_HEAD_THREADS / VNL_HEAD_GROUP)) + tid / VNL_HEAD_GROUP;
@@ -1056,10 +1064,7 @@ __global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_head_kernel(vnl_ppo_
     const float g_tlp = -inv_n * dmin * rho;      // d policy_loss / d target_log_prob
     const float g_ent = -a.entropy_cost * inv_n;  // d entropy_loss / d entropy_n
     const float verr = a.vs[n] - a.baseline[n];
-    if (lane == 0) {
-      s_pl += -fminf(s1, s2), s_vl += verr * verr, s_ent += ent;
-      a.g_baseline[n] = -0.5f * verr * inv_n;  // v_loss = 0.25 mean(verr^2)
-    }
+    if (lane == 0) s_pl += -fminf(s1, s2), s_vl += verr * verr, s_ent += ent;  // (d v_loss / d baseline: vnl_ppo_gae_kernel)
     float* gl = a.g_logits + (size_t)n * 2 * A;
     for (int k = lane; k < A; k += VNL_HEAD_GROUP) {
       const float sraw = lg[A + k], scale = (vnl_softplus(sraw) + a.min_std) * a.var_scale;
@@ -1089,6 +1094,9 @@ __global__ void __launch_bounds__(VNL_HEAD_THREADS) vnl_ppo_head_kernel(vnl_ppo_
 
 __global__ void vnl_ppo_finish_kernel(vnl_ppo_head_args a, const float* stats, int nblk) {
   // one 64-lane wave: lane l sums partials l, l+64, ... (fixed order), then a shuffle tree
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int lane = (int)threadIdx.x;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int b = lane; b < nblk; b += VNL_FINISH_THREADS)

@@ -272,7 +272,11 @@ extern "C" int vnl_policy_profile_stamps(long long* out) {
 
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-template <bool TRAIN>
+// MODE 0: acting (sampling, no intermediates).  MODE 1: training form -- no sampling, every intermediate the backward pass reads
+// goes to t.  MODE 2: training form from the FIRST encoder layer's Dense output on (t.encH[0], made by a GEMM launch of
+// csrc/vnl_ppo.hip): without the 16 x 795 trajectory tile the workgroup's LDS drops from 132 KB to 97 KB, so that workgroups of
+// the value MLP's GEMMs stay resident beside it.
+template <int MODE>
 __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel_t(PolicyDev p, const float* __restrict__ params,
                                                               const float* __restrict__ obs_mean,
                                                               const float* __restrict__ obs_std,
@@ -292,20 +296,28 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel_t(PolicyDev p, con
   const int e0 = blockIdx.x * PT, tid = threadIdx.x;
   const int nrow = min(PT, batch - e0);
 
+  constexpr bool TRAIN = MODE != 0;
+  if (TRAIN) __builtin_amdgcn_s_setprio(3);  // (beside the value MLP's chip-filling GEMMs: this chain is the step's critical path)
   POL_STAMP(0);
-  // traj tile -> A (rows beyond the batch are zero).  The tile's rows are one contiguous chunk of the input.
-  load_tile(traj + (size_t)e0 * p.traj_size, nrow, p.traj_size, A, p.ldA, nullptr, nullptr);
+  float *X = A, *Y = B;
+  int ldx = p.ldA, ldy = p.ldB, K = p.traj_size;
+  if (MODE == 2) {
+    load_tile(t.encH[0] + (size_t)e0 * p.enc[0], nrow, p.enc[0], Y, ldy, nullptr, nullptr);
+  } else {
+    // traj tile -> A (rows beyond the batch are zero).  The tile's rows are one contiguous chunk of the input.
+    load_tile(traj + (size_t)e0 * p.traj_size, nrow, p.traj_size, A, p.ldA, nullptr, nullptr);
+  }
   __syncthreads();
   POL_STAMP(1);
   // ---- encoder: Dense -> ReLU -> LayerNorm   (intention_policy_network.py:29-41)
-  float *X = A, *Y = B;
-  int ldx = p.ldA, ldy = p.ldB, K = p.traj_size;
   for (int l = 0; l < p.n_enc; l++) {
-    dense_tile(X, ldx, K, params, p.enc_w[l], p.enc_b[l], p.enc[l], Y, ldy, true, P);
-    POL_STAMP(2 + 2 * l);
-    if (TRAIN) {
-      store_tile(Y, ldy, nrow, p.enc[l], t.encH[l], e0);
-      __syncthreads();  // (LayerNorm works in place, a wave per row)
+    if (!(MODE == 2 && l == 0)) {
+      dense_tile(X, ldx, K, params, p.enc_w[l], p.enc_b[l], p.enc[l], Y, ldy, true, P);
+      POL_STAMP(2 + 2 * l);
+      if (TRAIN) {
+        store_tile(Y, ldy, nrow, p.enc[l], t.encH[l], e0);
+        __syncthreads();  // (LayerNorm works in place, a wave per row)
+      }
     }
     layer_norm_rows<TRAIN>(Y, ldy, p.enc[l], params + p.enc_g[l], params + p.enc_be[l], t.encS[l], e0, nrow);
     __syncthreads();
@@ -422,6 +434,8 @@ struct vnl_policy {
   int device, max_batch;
   int64_t nparams;
   size_t lds_bytes;
+  PolicyDev d2;       // MODE 2 (training form from the first Dense output on): no trajectory tile, both activation buffers narrow
+  size_t lds_bytes2;
 };
 
 extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, int32_t device, vnl_policy** out) {
@@ -514,12 +528,16 @@ extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, in
     delete p;
     return pfail(VNL_ERR_UNSUPPORTED, "network too wide for the 16-env LDS tile");
   }
+  p->d2 = d, p->d2.ldA = d.ldB;
+  p->lds_bytes2 = (size_t)PT * (2 * d.ldB + pw) * sizeof(float);
   p->device = device, p->max_batch = max_batch;
   if (p->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)p->lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+      e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes2);
     if (e != hipSuccess) {
       delete p;
       return pfail(VNL_ERR_HIP, hipGetErrorString(e));
@@ -546,7 +564,7 @@ extern "C" int vnl_policy_forward(vnl_policy* p, const float* params, const floa
   if ((obs_mean == nullptr) != (obs_std == nullptr)) return pfail(VNL_ERR_ARG, "obs_mean / obs_std must both be given or both null");
   if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
   int grid = (batch + PT - 1) / PT;
-  hipLaunchKernelGGL(vnl_policy_kernel_t<false>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
+  hipLaunchKernelGGL(vnl_policy_kernel_t<0>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
                      obs_mean, obs_std, traj, obs, eps_latent, eps_action, (int)batch, (int)deterministic, action,
                      raw_action, log_prob, logits, latent_mean, latent_logvar, rand_action, rand_log_prob, PolicyTrainOut{});
   hipError_t e = hipGetLastError();
@@ -558,12 +576,17 @@ extern "C" int vnl_policy_forward(vnl_policy* p, const float* params, const floa
 // no sampling; besides the logits and the latent heads it leaves every intermediate the backward pass reads.
 int vnl_policy_forward_train_(vnl_policy* p, const float* params, const float* obs_mean, const float* obs_std, const float* traj,
                               const float* obs, const float* eps_latent, int32_t batch, float* logits, float* latent_mean,
-                              float* latent_logvar, const PolicyTrainOut* out, void* stream) {
+                              float* latent_logvar, const PolicyTrainOut* out, int from_first_dense, void* stream) {
   if (!p || !params || !traj || !obs || !eps_latent || !logits || !latent_mean || !latent_logvar || !out)
     return pfail(VNL_ERR_ARG, "vnl_policy_forward_train_: null argument");
   if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
   const int grid = (batch + PT - 1) / PT;
-  hipLaunchKernelGGL(vnl_policy_kernel_t<true>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
+  if (from_first_dense)
+    hipLaunchKernelGGL(vnl_policy_kernel_t<2>, dim3(grid), dim3(PTHREADS), p->lds_bytes2, (hipStream_t)stream, p->d2, params,
+                       obs_mean, obs_std, traj, obs, eps_latent, (const float*)nullptr, (int)batch, 1, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, logits, latent_mean, latent_logvar, (const float*)nullptr, (float*)nullptr, *out);
+  else
+  hipLaunchKernelGGL(vnl_policy_kernel_t<1>, dim3(grid), dim3(PTHREADS), p->lds_bytes, (hipStream_t)stream, p->d, params,
                      obs_mean, obs_std, traj, obs, eps_latent, (const float*)nullptr, (int)batch, 1, (float*)nullptr, (float*)nullptr,
                      (float*)nullptr, logits, latent_mean, latent_logvar, (const float*)nullptr, (float*)nullptr, *out);
   hipError_t e = hipGetLastError();

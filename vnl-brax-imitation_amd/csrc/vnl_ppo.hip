@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) sum_slabs_kernel(float* out, const float*
 // weight gradient, the last one (the ones-row of the operand) to the bias gradient.
 #define VNL_MAX_JOBS 28
 struct ReduceJobs {
-  int njobs;
+  int njobs, prio;
   unsigned start4[VNL_MAX_JOBS + 1];
   float* out[VNL_MAX_JOBS];
   float* bias_out[VNL_MAX_JOBS];
@@ -318,6 +318,7 @@ struct ReduceJobs {
   unsigned real[VNL_MAX_JOBS];  // elements of one slab that exist (rows * cols with the ones row)
 };
 __global__ void __launch_bounds__(256) reduce_jobs_kernel(ReduceJobs J) {
+  if (J.prio == 3) __builtin_amdgcn_s_setprio(3);
   const unsigned total4 = J.start4[J.njobs];
   for (unsigned i4 = blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += gridDim.x * 256) {
     int j = 0;
@@ -723,9 +724,8 @@ struct vnl_ppo_update {
   std::vector<float*> encH, encY, encS, decH, decY, decS, valZ, valA;
   vnl_policy* fused = nullptr;  // the intention network's forward pass as ONE launch (csrc/vnl_policy.hip in its training form);
                                 // null: the network is outside that kernel's limits -> layer by layer
-  bool layered = true;          // the layer-by-layer forward is the default: measured 0.462 ms per step against 0.496 with the fused
-                                // kernel, whose 132 KB of LDS per workgroup keeps the value MLP's GEMMs off 160 CUs while it runs
-                                // (tools/ppo_update_bench.py --fused switches it on)
+  int fwd_mode = 2;  // the intention network's forward: 0 layer by layer, 1 ONE fused launch, 2 first Dense as a GEMM + the rest fused
+                     // (tools/ppo_update_bench.py --fwd-mode; measured per minibatch step: see DESIGN section 5)
   int prio = 3;                 // wave priority of the intention network's GEMMs (tuning knob: tile = -2 switches it off)
 };
 
@@ -749,8 +749,8 @@ extern "C" void vnl_ppo_update_destroy(vnl_ppo_update* u) {
 
 // tuning knob of tools/ppo_update_bench.py (not part of include/vnl.h): force the GEMM tile (64 / 128; 0 = by shape)
 extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
-  if (u && tile == -1) {  // the intention network's forward as one fused launch
-    u->layered = false;
+  if (u && tile <= -10 && tile >= -12) {  // the intention network's forward: -10 layer by layer, -11 one fused launch, -12 GEMM + fused
+    u->fwd_mode = -10 - tile;
     return VNL_OK;
   }
   if (u && tile == -2) {
@@ -978,8 +978,8 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
   // as soon as its grouped weight-gradient launch is done, beside the value MLP's last GEMMs
   SlabPool pool{u->slabs, u->slab_floats - u->slab_floats_p, 0, {}, u->tile};
   SlabPool poolP{u->slabs + (u->slab_floats - u->slab_floats_p), u->slab_floats_p, 0, {}, u->tile};
-  pool.jobs.njobs = 0, pool.jobs.start4[0] = 0;
-  poolP.jobs.njobs = 0, poolP.jobs.start4[0] = 0;
+  pool.jobs.njobs = 0, pool.jobs.start4[0] = 0, pool.jobs.prio = 0;
+  poolP.jobs.njobs = 0, poolP.jobs.start4[0] = 0, poolP.jobs.prio = u->prio;
   pool.wg_target = poolP.wg_target = u->wg_target;
   GemmGroup group;
   group.n = 0;
@@ -1027,7 +1027,7 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       const DenseP& d = u->val[nvl - 1];
       hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
     }
-    if (u->fused && !u->layered) {
+    if (u->fused && u->fwd_mode != 0) {
       // the whole intention network as ONE launch: a 16-row tile goes through encoder, latent heads, reparameterisation and
       // decoder without leaving LDS (csrc/vnl_policy.hip, the acting path's kernel in its training form), writing what
       // the backward pass reads; it takes the raw trajectory / observation, so it does not wait for prep_kernel
@@ -1036,8 +1036,12 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       for (size_t i = 0; i < u->dec.size(); i++)
         if (u->dec[i].ln) to.decH[i] = u->decH[i], to.decS[i] = u->decS[i], to.decY[i] = u->decY[i];
       to.ml = u->ml, to.D0 = u->D0;
+      if (u->fwd_mode == 2) {  // the first Dense (K = traj_size: most of the network's arithmetic) as a GEMM launch, the rest fused
+        const DenseP& d = u->enc[0];
+        GP.run(false, false, EPI_RELU, u->trajp, u->ntp, P + d.w, d.out, u->encH[0], d.out, N, d.out, d.in, P + d.b);
+      }
       const int rc = vnl_policy_forward_train_(u->fused, P, bt->obs_mean, bt->obs_std, bt->traj, bt->obs, bt->eps_latent, N, u->logits,
-                                               u->mean, u->logvar, &to, sp2);
+                                               u->mean, u->logvar, &to, u->fwd_mode == 2, sp2);
       if (rc != VNL_OK) return rc;
     } else {
     // encoder (intention_policy_network.py:20-44)
@@ -1074,7 +1078,6 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       }
     }
     }
-    PCHK(hipEventRecord(u->ev[1], sp2));
     // ---------------- loss head: GAE, clipped surrogate, value / entropy / KL terms and d loss / d (network outputs)
     {
       vnl_ppo_head_args a{};
@@ -1087,9 +1090,12 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       a.min_std = hp->min_std, a.var_scale = hp->var_scale, a.normalize_advantage = hp->normalize_advantage;
       a.g_logits = u->gl, a.g_baseline = u->gb, a.g_lat_mean = u->gklm, a.g_lat_logvar = u->gkll;
       a.vs = u->vs, a.advantages = u->adv, a.metrics = metrics;
-      // GAE needs the value outputs only: it runs while the intention network's forward is still in flight
+      // GAE, the advantage statistics and d v_loss / d baseline need the value outputs only: they run on the value stream as
+      // soon as the value MLP's forward is done, and its BACKWARD pass follows at once (below) -- the three big GEMMs of that
+      // pass no longer wait for the intention network's forward
       int rc = vnl_ppo_head_phase_(&a, u->headws, stream, 1);
       if (rc != VNL_OK) return rc;
+      PCHK(hipEventRecord(u->ev[2], st));
       // metrics[8] = prediction_corr (a metric only), in the same slack; NaN ("not computed", never a fake 0.0) when the 2T
       // rows do not fit in LDS -- the same rule as the torch backend (intention_losses.py: _corr_fits)
       const size_t lds = ((size_t)2 * u->T * u->B + 2 * u->T) * sizeof(float);
@@ -1098,14 +1104,12 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
                            u->T, u->B, metrics + 8);
       else
         PCHK(hipMemsetAsync(metrics + 8, 0xff, sizeof(float), st));  // 0xffffffff: a quiet NaN
-      PCHK(hipStreamWaitEvent(st, u->ev[1], 0));
-      rc = vnl_ppo_head_phase_(&a, u->headws, stream, 2);
+      // the per-sample head (policy / entropy / KL terms, d loss / d logits, d loss / d latent heads) on the intention
+      // network's stream, right behind its forward pass and in front of its backward pass
+      PCHK(hipStreamWaitEvent(sp2, u->ev[2], 0));
+      rc = vnl_ppo_head_phase_(&a, u->headws, sp2, 2);
       if (rc != VNL_OK) return rc;
     }
-  }
-  if (part != 2) {
-    PCHK(hipEventRecord(u->ev[2], st));
-    PCHK(hipStreamWaitEvent(sp2, u->ev[2], 0));
   }
   // ---------------- backward: value MLP (the bootstrap rows carry no gradient: stop_gradient, intention_losses.py:137)
   if (part != 2) {
