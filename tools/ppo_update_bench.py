@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile of the hand-written path (64 / 128)")
     ap.add_argument("--wg-target", type=int, default=0, help="workgroups a split-K weight gradient is split up to (default 256)")
     ap.add_argument("--fwd-mode", type=int, default=-1, help="the intention network's forward: 0 layer by layer, 1 one fused launch (csrc/vnl_policy.hip, training form), 2 first Dense as a GEMM + the rest fused (default)")
+    ap.add_argument("--fused-threads", type=int, default=0, help="threads of the fused part of the forward (256 / 512 / 1024)")
     ap.add_argument("--noprio", action="store_true", help="no raised wave priority for the intention network's GEMMs")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses, running_statistics
@@ -53,6 +54,8 @@ def main():
             assert upd.lib.vnl_ppo_update_tune(upd.h, a.tile, a.wg_target) == 0
         if a.fwd_mode >= 0:
             assert upd.lib.vnl_ppo_update_tune(upd.h, -10 - a.fwd_mode, 0) == 0
+        if a.fused_threads:
+            assert upd.lib.vnl_ppo_update_tune(upd.h, -a.fused_threads, 0) == 0
         if a.noprio:
             assert upd.lib.vnl_ppo_update_tune(upd.h, -2, 0) == 0
 

@@ -26,6 +26,7 @@
 
 #define PT 16          /* envs per workgroup = rows of the 16x16x4 MFMA tile */
 #define PTHREADS 1024  /* 16 waves: four per SIMD, some compute while the others wait for their weight loads */
+#define PNT ((int)blockDim.x) /* threads of THIS launch: 1024, or 256 for the training form that starts at the first Dense output */
 #define LN_EPS 1e-6f   /* flax.linen.LayerNorm default */
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -42,7 +43,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // W[k0 + l / 16][column of l % 16];  D: lane l, register i holds Y[(l / 16) * 4 + i][column of l % 16].
 __device__ __forceinline__ int dense_col_groups(int N) {  // power of two <= 16 covering ceil(N / 64)
   int G = (N + 63) >> 6, Gp = 1;
-  while (Gp < G && Gp < PTHREADS / 64) Gp <<= 1;
+  while (Gp < G && Gp < PNT / 64) Gp <<= 1;
   return Gp;
 }
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ void dense_tile_t(const float* X, int ldx, int K, con
   const float* __restrict__ bias2 = params + b2_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int G = (N + 63) >> 6, Gp = dense_col_groups(N), S = (PTHREADS / 64) / Gp;
+  const int G = (N + 63) >> 6, Gp = dense_col_groups(N), S = (PNT / 64) / Gp;
   const int g0 = wave & (Gp - 1), s = wave / Gp;
   const int N4 = (N + 3) & ~3;
   const int T = (K + 3) >> 2, Ts = (T + S - 1) / S;  // k-steps of 4, per slice
@@ -64,7 +65,7 @@ __device__ __forceinline__ void dense_tile_t(const float* X, int ldx, int K, con
   float bias_r[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int e = tid + q * PTHREADS;
+    const int e = tid + q * PNT;
     const int c = e % N;
     bias_r[q] = e < PT * N ? (c < split ? bias[c] : bias2[c - split]) : 0.f;
   }
@@ -142,10 +143,10 @@ __device__ __forceinline__ void dense_tile_t(const float* X, int ldx, int K, con
   };
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int e = tid + q * PTHREADS;
+    const int e = tid + q * PNT;
     if (e < PT * N) finish(e, bias_r[q]);
   }
-  for (int e = tid + 4 * PTHREADS; e < PT * N; e += PTHREADS) finish(e, e % N < split ? bias[e % N] : bias2[e % N - split]);
+  for (int e = tid + 4 * PNT; e < PT * N; e += PNT) finish(e, e % N < split ? bias[e % N] : bias2[e % N - split]);
   __syncthreads();
 }
 
@@ -166,7 +167,7 @@ __device__ __forceinline__ void dense_tile(const float* X, int ldx, int K, const
 
 // the tile's rows (LDS, ld) -> dst[(e0 + r) * width + c], r < nrow: what the training form leaves for the backward pass
 __device__ __forceinline__ void store_tile(const float* src, int ld, int nrow, int width, float* __restrict__ dst, int e0) {
-  for (int i = threadIdx.x; i < nrow * width; i += PTHREADS) {
+  for (int i = threadIdx.x; i < nrow * width; i += PNT) {
     const int r = i / width, c = i - r * width;
     dst[(size_t)(e0 + r) * width + c] = src[r * ld + c];
   }
@@ -179,7 +180,7 @@ __device__ __forceinline__ void layer_norm_rows(float* Y, int ldy, int N, const 
                                                 const float* __restrict__ be, float* __restrict__ stats = nullptr, int e0 = 0,
                                                 int nrow = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int RPW = PT / (PTHREADS / 64);  // rows per wave
+  const int RPW = PT / (PNT / 64);  // rows per wave
   // scale / bias of the first 256 columns are requested before the row statistics (their latency passes under them)
   float gr[4], br[4];
 #pragma unroll
@@ -232,16 +233,16 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int nro
   if (((uintptr_t)src & 15) == 0) {
     const v4f* s4 = (const v4f*)src;
     const int n4 = n >> 2;
-    for (int base = 0; base < n4; base += 4 * PTHREADS) {
+    for (int base = 0; base < n4; base += 4 * PNT) {
       v4f v[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int i = base + u * PTHREADS + tid;
+        const int i = base + u * PNT + tid;
         v[u] = s4[i < n4 ? i : 0];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int i = base + u * PTHREADS + tid;
+        const int i = base + u * PNT + tid;
         if (i < n4) {
 #pragma unroll
           for (int q = 0; q < 4; q++) put(4 * i + q, v[u][q]);
@@ -250,8 +251,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int nro
     }
     done = n4 << 2;
   }
-  for (int i = done + tid; i < n; i += PTHREADS) put(i, src[i]);
-  for (int i = n + tid; i < PT * width; i += PTHREADS) {
+  for (int i = done + tid; i < n; i += PNT) put(i, src[i]);
+  for (int i = n + tid; i < PT * width; i += PNT) {
     const int r = i / width, c = i - r * width;
     dst[r * ld + c] = 0.f;
   }
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel_t(PolicyDev p, con
   POL_STAMP(10);
   if (TRAIN) store_tile(Y, ldy, nrow, 2 * p.latent, t.ml, e0);
   // ---- z = mean + eps * exp(logvar / 2) (ipn:73-76); decoder input [z | normalised obs] -> X
-  for (int i = tid; i < PT * p.latent; i += PTHREADS) {
+  for (int i = tid; i < PT * p.latent; i += PNT) {
     int r = i / p.latent, c = i - r * p.latent;
     float mu = Y[r * ldy + c], lv = Y[r * ldy + p.latent + c];
     float z = 0.f;
@@ -379,13 +380,13 @@ __global__ void __launch_bounds__(PTHREADS) vnl_policy_kernel_t(PolicyDev p, con
   POL_STAMP(20);
   // ---- distribution (brax NormalTanhDistribution; ppo_networks.py:56-83): X holds logits [loc | s]
   const int na = p.act_size;
-  for (int i = tid; i < PT * 2 * na; i += PTHREADS) {
+  for (int i = tid; i < PT * 2 * na; i += PNT) {
     int r = i / (2 * na), c = i - r * 2 * na;
     if (r < nrow) logits[(size_t)(e0 + r) * 2 * na + c] = X[r * ldx + c];
   }
   if (TRAIN) return;  // (sampling belongs to acting; the loss head works from the logits)
   float* lp = Y;  // per-(env, action) log-prob terms
-  for (int i = tid; i < PT * na; i += PTHREADS) {
+  for (int i = tid; i < PT * na; i += PNT) {
     int r = i / na, c = i - r * na;
     float term = 0.f;
     if (r < nrow) {
@@ -436,7 +437,31 @@ struct vnl_policy {
   size_t lds_bytes;
   PolicyDev d2;       // MODE 2 (training form from the first Dense output on): no trajectory tile, both activation buffers narrow
   size_t lds_bytes2;
+  int threads2;
 };
+
+// threads of the MODE 2 launch (256 / 512 / 1024) and the LDS it then needs: the partial-sum buffer shrinks with the wave count
+// (tools/ppo_update_bench.py --fused-threads; measured per PPO minibatch step: 1024 -> 0.430 ms, 512 -> 0.451, 256 -> 0.458)
+int vnl_policy_set_threads2_(vnl_policy* p, int threads) {
+  if (!p || (threads != 256 && threads != 512 && threads != 1024)) return VNL_ERR_ARG;
+  const PolicyDev& d = p->d;
+  int pw2 = 0;
+  bool ok2 = true;
+  auto upd2 = [&](int n) {
+    int G = (n + 63) / 64, Gp = 1;
+    while (Gp < G && Gp < threads / 64) Gp <<= 1;
+    if (G > Gp) ok2 = false;
+    int w = (threads / 64 / Gp) * ((n + 3) & ~3);
+    pw2 = w > pw2 ? w : pw2;
+  };
+  for (int l = 0; l < d.n_enc; l++) upd2(d.enc[l]);
+  for (int l = 0; l < d.n_dec; l++) upd2(d.dec[l]);
+  upd2(d.latent), upd2(2 * d.latent);
+  if (!ok2) return VNL_ERR_UNSUPPORTED;
+  p->threads2 = threads;
+  p->lds_bytes2 = (size_t)PT * (2 * d.ldB + pw2) * sizeof(float);
+  return VNL_OK;
+}
 
 extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, int32_t device, vnl_policy** out) {
   if (!s || !out) return pfail(VNL_ERR_ARG, "vnl_policy_create: null argument");
@@ -529,7 +554,7 @@ extern "C" int vnl_policy_create(const vnl_policy_spec* s, int32_t max_batch, in
     return pfail(VNL_ERR_UNSUPPORTED, "network too wide for the 16-env LDS tile");
   }
   p->d2 = d, p->d2.ldA = d.ldB;
-  p->lds_bytes2 = (size_t)PT * (2 * d.ldB + pw) * sizeof(float);
+  (void)vnl_policy_set_threads2_(p, PTHREADS);
   p->device = device, p->max_batch = max_batch;
   if (p->lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)vnl_policy_kernel_t<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -582,7 +607,7 @@ int vnl_policy_forward_train_(vnl_policy* p, const float* params, const float* o
   if (batch <= 0 || batch > p->max_batch) return pfail(VNL_ERR_ARG, "batch out of range");
   const int grid = (batch + PT - 1) / PT;
   if (from_first_dense)
-    hipLaunchKernelGGL(vnl_policy_kernel_t<2>, dim3(grid), dim3(PTHREADS), p->lds_bytes2, (hipStream_t)stream, p->d2, params,
+    hipLaunchKernelGGL(vnl_policy_kernel_t<2>, dim3(grid), dim3(p->threads2), p->lds_bytes2, (hipStream_t)stream, p->d2, params,
                        obs_mean, obs_std, traj, obs, eps_latent, (const float*)nullptr, (int)batch, 1, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, logits, latent_mean, latent_logvar, (const float*)nullptr, (float*)nullptr, *out);
   else

@@ -26,6 +26,7 @@ struct PolicyTrainOut {
 };
 
 struct vnl_policy;
+int vnl_policy_set_threads2_(vnl_policy* p, int threads);
 int vnl_policy_forward_train_(vnl_policy* p, const float* params, const float* obs_mean, const float* obs_std, const float* traj,
                               const float* obs, const float* eps_latent, int32_t batch, float* logits, float* latent_mean,
                               float* latent_logvar, const PolicyTrainOut* out, int from_first_dense /* encH[0] is given (a GEMM made it): start at its LayerNorm */,

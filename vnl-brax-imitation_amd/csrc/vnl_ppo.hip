@@ -753,6 +753,9 @@ extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
     u->fwd_mode = -10 - tile;
     return VNL_OK;
   }
+  if (u && (tile == -256 || tile == -512 || tile == -1024)) {  // threads of the fused part of the intention network's forward
+    return u->fused ? vnl_policy_set_threads2_(u->fused, -tile) : VNL_OK;
+  }
   if (u && tile == -2) {
     u->prio = 0;
     return VNL_OK;
