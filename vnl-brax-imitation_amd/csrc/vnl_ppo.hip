@@ -326,9 +326,15 @@ __global__ void __launch_bounds__(256) reduce_jobs_kernel(ReduceJobs J) {
     const unsigned e = (i4 - J.start4[j]) * 4, tot = J.tot[j];
     const float* p = J.part[j] + e;
     f32x4 a = *(const f32x4*)p;
-    for (int s = 1; s < J.S[j]; s++) {
-      const f32x4 b = *(const f32x4*)(p + (size_t)s * tot);
-      a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    // eight slabs' loads in flight at once, summed in slab order (a load per trip made every slab a memory round trip)
+    const int S = J.S[j];
+    for (int s0 = 1; s0 < S; s0 += 8) {
+      f32x4 b[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) b[k] = *(const f32x4*)(p + (size_t)(s0 + k < S ? s0 + k : 0) * tot);
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (s0 + k < S) a.x += b[k].x, a.y += b[k].y, a.z += b[k].z, a.w += b[k].w;
     }
     const float v[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
