@@ -122,3 +122,40 @@ def test_hip_update_matches_autograd_and_numpy(cfg):
         ref = parts[name] if name == "vs" else None
         if ref is not None:
             assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-5, name
+
+
+def test_forward_routes_of_the_intention_network_agree():
+    """The intention network's forward pass has three routes (csrc/vnl_ppo.hip: layer by layer; ONE fused launch of the acting
+    path's kernel in its training form; first Dense as a GEMM + the rest fused -- the default).  Same network, same inputs:
+    losses and every gradient tensor must agree to float32 rounding (the fused routes accumulate a Dense in K slices)."""
+    from vnl_brax_imitation_amd.ppo_imitation import hip_update, running_statistics
+
+    cfg = dict(traj=795, obs=232, act=30, latent=64, enc=(256, 128), dec=(128, 256), val=(1024, 1024), T=20, B=128)
+    nets, flat, data, norm, noise = _make(**cfg)
+    dev = torch.device("cuda:0")
+    to = lambda t: t.to(dev)  # noqa: E731
+    ndev = running_statistics.RunningStatisticsState(to(norm.count), to(norm.mean), to(norm.summed_variance), to(norm.std))
+    fl, dd, nn = to(flat).contiguous(), data.map(to), {k: to(v) for k, v in noise.items()}
+    out = {}
+    for mode in (0, 1, 2):
+        upd = hip_update.HipPPOUpdate(nets, cfg["T"], cfg["B"], dev, **HP)
+        assert upd.lib.vnl_ppo_update_tune(upd.h, -10 - mode, 0) == 0
+        grads = torch.full((flat.numel(),), float("nan"), device=dev)
+        mt = upd.grad(fl, ndev, dd, nn, grads)
+        torch.cuda.synchronize()
+        out[mode] = (grads.cpu().numpy().astype(np.float64), mt.cpu().numpy().astype(np.float64))
+    n_pol = nets.policy_network.layout.size
+    for mode in (0, 1):
+        g, m = out[mode]
+        gr, mr = out[2]
+        assert np.isfinite(g).all()
+        assert np.abs(m[:5] - mr[:5]).max() <= 2e-6 * max(1.0, np.abs(mr[:5]).max()), (mode, m[:5], mr[:5])
+        worst = 0.0
+        for lay, off0 in ((nets.policy_network.layout, 0), (nets.value_network.layout, n_pol)):
+            for name, (off, shape) in lay.entries.items():
+                n = int(np.prod(shape))
+                a, b = g[off0 + off: off0 + off + n], gr[off0 + off: off0 + off + n]
+                e = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+                worst = max(worst, e)
+                assert e < 1e-5, (mode, name, e)
+        print(f"\n[forward route {mode} vs default] worst per-tensor gradient difference {worst:.2e}")
