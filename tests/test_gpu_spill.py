@@ -2,7 +2,7 @@
 
 Round 1 saw a build of the step kernel that had slipped to 256 VGPRs + scratch give wrong results on the GPU and
 answered by refusing such builds.  A well-defined program computes the same thing whether or not the compiler spills,
-so this test compiles the SAME sources under a 128-VGPR cap (csrc/build.py --spill: 212 bytes of scratch and ~230
+so this test compiles the SAME sources under a 128-VGPR cap (csrc/build.py --spill: hundreds of bytes of scratch and ~130-230
 spilled registers per lane in the step kernel) and holds that build to the same oracle bounds as the product build,
 and to agreement with the product build itself."""
 import numpy as np

@@ -101,7 +101,7 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, kno
         stderr = remarks
     r = _R()
     # Register budget of the env kernels: a PERFORMANCE check (two waves per SIMD and no private-memory stack are what
-    # the measured numbers assume), not a correctness one -- the spill variant runs the parity tests with 212 bytes of
+    # the measured numbers assume), not a correctness one -- the spill variant runs the parity tests with hundreds of bytes of
     # scratch per lane.  Fails closed: if the compiler's remarks for the env kernels are not found, the build is
     # rejected rather than waved through.
     usage = resource_usage(r.stderr)
