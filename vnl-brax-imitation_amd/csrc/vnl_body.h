@@ -409,40 +409,61 @@ struct EnvWaveT {
   //  (3) per dof, in parallel: cdof from the parent's world pose and the local anchor / axis.
   VNL_HD void kinematics() const {
     int A = LO(P), Bf = LO(P) + 7 * MI(nbody);  // 7 floats per body: pos(3) quat(4)
-    VNL_FOR(b, MI(nbody)) {
-      V3 pos = v3(vreal(0.), vreal(0.), vreal(0.));
-      Q4 quat = Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)};
-      if (b > 0) {
-        pos = t3(m.body_pos, b), quat = t4(m.body_quat, b);
-        int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
-        for (int k = 0; k < jn; k++) {
-          int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-          if (m.jnt_type[j] == VNL_JNT_FREE) {
-            pos = ld3(LO(qpos) + qa);
-            quat = ld4(LO(qpos) + qa + 3);
-            vreal n = sqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
-            vreal inv = n > vreal(0.) ? vreal(1.) / n : vreal(1.);
-            quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
-            s[LO(qpos) + qa + 3] = quat.w, s[LO(qpos) + qa + 4] = quat.x, s[LO(qpos) + qa + 5] = quat.y,
-                            s[LO(qpos) + qa + 6] = quat.z;  // normalised quaternion written back
-          } else {
-            V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
-            V3 anchor = qrot(jp, quat) + pos;
-            st6(LO(cdof) + 6 * da, S6{qrot(jax, quat), anchor});  // (axis, anchor) in the parent frame, for phase 3
-            vreal ang = s[LO(qpos) + qa] - m.jnt_qpos0[j];
-            vreal sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
-            quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
-            pos = anchor - qrot(jp, quat);
-          }
-        }
+    // The model is one tree rooted at body 1 (vnl_lib.hip checks it), so a free joint can only sit there and every body
+    // from 2 on carries hinges only.  Bodies 0 (world) and 1 are therefore dealt with apart: their poses are final after
+    // phase 1 (no ancestor to compose with), and the loops over the OTHER bodies are hinge-only code over nbody - 2 items
+    // -- 64 for the rodent: one trip per region instead of two (66 bodies) with both joint types' code in each.
+    auto put_pose = [&](int base, int b, V3 pos, Q4 quat) {
+      st3(base + 7 * b, pos);
+      s[base + 7 * b + 3] = quat.w, s[base + 7 * b + 4] = quat.x, s[base + 7 * b + 5] = quat.y, s[base + 7 * b + 6] = quat.z;
+    };
+    auto hinge_chain = [&](int b, V3& pos, Q4& quat) {  // the body's hinges in turn: (axis, anchor) parked in cdof for phase 3
+      const int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+      for (int k = 0; k < jn; k++) {
+        const int j = ja + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+        V3 jp = t3(m.jnt_pos, j), jax = t3(m.jnt_axis, j);
+        V3 anchor = qrot(jp, quat) + pos;
+        st6(LO(cdof) + 6 * da, S6{qrot(jax, quat), anchor});  // (axis, anchor) in the parent frame, for phase 3
+        vreal ang = s[LO(qpos) + qa] - m.jnt_qpos0[j];
+        vreal sn = sin(vreal(0.5) * ang), cs = cos(vreal(0.5) * ang);
+        quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+        pos = anchor - qrot(jp, quat);
       }
-      st3(A + 7 * b, pos);
-      s[A + 7 * b + 3] = quat.w, s[A + 7 * b + 4] = quat.x, s[A + 7 * b + 5] = quat.y, s[A + 7 * b + 6] = quat.z;
+    };
+    VNL_FOR(k, MI(nbody) - 2) {
+      const int b = k + 2;
+      V3 pos = t3(m.body_pos, b);
+      Q4 quat = t4(m.body_quat, b);
+      hinge_chain(b, pos, quat);
+      put_pose(A, b, pos, quat);
+    }
+    VNL_SERIAL {  // the world body and the root body, into BOTH buffers of the composition rounds (which never touch them)
+      put_pose(A, 0, v3(vreal(0.), vreal(0.), vreal(0.)), Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)});
+      put_pose(Bf, 0, v3(vreal(0.), vreal(0.), vreal(0.)), Q4{vreal(1.), vreal(0.), vreal(0.), vreal(0.)});
+      if (MI(nbody) > 1) {
+        V3 pos = t3(m.body_pos, 1);
+        Q4 quat = t4(m.body_quat, 1);
+        if (MI(root_free)) {
+          const int qa = m.jnt_qposadr[m.body_jntadr[1]];
+          pos = ld3(LO(qpos) + qa);
+          quat = ld4(LO(qpos) + qa + 3);
+          vreal n = sqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
+          vreal inv = n > vreal(0.) ? vreal(1.) / n : vreal(1.);
+          quat = Q4{quat.w * inv, quat.x * inv, quat.y * inv, quat.z * inv};
+          s[LO(qpos) + qa + 3] = quat.w, s[LO(qpos) + qa + 4] = quat.x, s[LO(qpos) + qa + 5] = quat.y,
+                          s[LO(qpos) + qa + 6] = quat.z;  // normalised quaternion written back
+        } else {
+          hinge_chain(1, pos, quat);
+        }
+        put_pose(A, 1, pos, quat);
+        put_pose(Bf, 1, pos, quat);
+      }
     }
     VNL_SYNC();
     int src = A, dst = Bf;
     for (int r = 0; r < MI(jump_rounds); r++) {
-      VNL_FOR(b, MI(nbody)) {
+      VNL_FOR(k, MI(nbody) - 2) {
+        const int b = k + 2;
         int j = jump_of(r, b);
         V3 pos = ld3(src + 7 * b);
         Q4 quat = ld4(src + 7 * b + 3);
@@ -451,8 +472,7 @@ struct EnvWaveT {
           pos = ld3(src + 7 * j) + qrot(pos, pq);
           quat = qmul(pq, quat);
         }
-        st3(dst + 7 * b, pos);
-        s[dst + 7 * b + 3] = quat.w, s[dst + 7 * b + 4] = quat.x, s[dst + 7 * b + 5] = quat.y, s[dst + 7 * b + 6] = quat.z;
+        put_pose(dst, b, pos, quat);
       }
       VNL_SYNC();
       int t = src;
@@ -467,9 +487,20 @@ struct EnvWaveT {
       gq[4 * b] = q.w, gq[4 * b + 1] = q.x, gq[4 * b + 2] = q.y, gq[4 * b + 3] = q.z;
     }
     V3 O = ref_point();
-    VNL_FOR(j, MI(njnt)) {
-      int bd = m.jnt_body[j], da = m.jnt_dofadr[j];
-      if (m.jnt_type[j] == VNL_JNT_FREE) {
+    // cdof: the hinges (every joint but a free root's) ..
+    const int j0 = MI(root_free) ? 1 : 0;
+    VNL_FOR(k, MI(njnt) - j0) {
+      const int j = k + j0, bd = m.jnt_body[j], da = m.jnt_dofadr[j];
+      int p = parent_of(bd);
+      Q4 pq = ld4(src + 7 * p + 3);
+      S6 la = ld6(LO(cdof) + 6 * da);
+      V3 axis = qrot(la.a, pq), anchor = ld3(src + 7 * p) + qrot(la.l, pq);
+      st6(LO(cdof) + 6 * da, S6{axis, cross(axis, O - anchor)});
+    }
+    // .. and the free root's six
+    if (MI(root_free)) {
+      VNL_SERIAL {
+        const int j = m.body_jntadr[1], bd = 1, da = m.jnt_dofadr[j];
         M3 R = qmat(ld4(src + 7 * bd + 3));
         V3 off = O - ld3(src + 7 * bd);
         for (int t = 0; t < 3; t++) {
@@ -482,12 +513,6 @@ struct EnvWaveT {
           V3 ax = V3{R.a[t], R.a[3 + t], R.a[6 + t]};
           st6(LO(cdof) + 6 * (da + 3 + t), S6{ax, cross(ax, off)});
         }
-      } else {
-        int p = parent_of(bd);
-        Q4 pq = ld4(src + 7 * p + 3);
-        S6 la = ld6(LO(cdof) + 6 * da);
-        V3 axis = qrot(la.a, pq), anchor = ld3(src + 7 * p) + qrot(la.l, pq);
-        st6(LO(cdof) + 6 * da, S6{axis, cross(axis, O - anchor)});
       }
     }
     VNL_SYNC_GLOBAL();  // (xpos / xquat went to the state buffers: read across lanes from here on)
