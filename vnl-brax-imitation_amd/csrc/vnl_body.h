@@ -1710,6 +1710,7 @@ struct EnvWaveT {
     S6 acc = S6{v3(0, 0, 0), v3(0, 0, 0)};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      if (k >= MI(path_runs)) break;  // (no body of this model has more runs: two for the rodent)
       const int sg = seg[k], b = sg & 0xff, e = sg >> 8;  // (an unused run is 0 | 0 << 8: Q[0] - Q[0])
       S6 qe = ld6(Q + 6 * e), qb = ld6(Q + 6 * b);
       acc = S6{acc.a + (qe.a - qb.a), acc.l + (qe.l - qb.l)};

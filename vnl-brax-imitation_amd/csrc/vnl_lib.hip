@@ -250,6 +250,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     {
       const auto& dpar = I("dof_parentid");
       std::vector<int> seg(8 * (size_t)nb, 0);  // per body: 4 runs of dofs, then 4 runs of ancestor bodies (incl. itself)
+      int most = 1;
       for (int b = 1; b < nb; b++) {
         {
           std::vector<int> anc;
@@ -263,6 +264,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
             seg[8 * b + 4 + nseg++] = anc[i] | ((anc[j] + 1) << 8);
             i = j + 1;
           }
+          most = nseg > most ? nseg : most;
         }
         std::vector<int> path;
         for (int dd = lastdof[b] < nv ? lastdof[b] : -1; dd >= 0; dd = dpar[dd]) path.push_back(dd);
@@ -275,7 +277,9 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
           seg[8 * b + nseg++] = path[i] | ((path[j] + 1) << 8);
           i = j + 1;
         }
+        most = nseg > most ? nseg : most;
       }
+      d.path_runs = most;
       UPI(body_pathseg, seg)
     }
     int bdepth = 0;
@@ -571,7 +575,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
 
 static VnlDims dims_of(const DevModel& d) {
   return VnlDims{d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ncg, d.ncon, d.nlimit, d.nefc, d.nM, d.iterations, d.ls_iterations, d.eulerdamp,
-                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton, d.blk_cfg};
+                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton, d.blk_cfg, d.path_runs};
 }
 
 static void layout(vnl_env* env) {

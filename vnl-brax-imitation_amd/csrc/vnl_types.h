@@ -38,6 +38,7 @@ struct DevModel {
   int fac_steps; /* number of steps of the factorisation schedule */
   int fac_nleaf; /* low byte: leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand
                     side), else 0; bits 8..: depth of the deepest of the rows 64 .. (second lane set) */
+  int path_runs; /* most runs of consecutive dofs / ancestor bodies any body's path has (<= 4): EnvWave::path_sum walks that many */
   int blk_cfg;   /* EnvWave::blk_apply: trips of the row form | trips of the column form << 4 | combine steps (row) << 8 | (column) << 12; 0 = no table */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
   vreal dt, tolerance, ls_tolerance, scale /* meaninertia * max(1,nv) */;
@@ -120,7 +121,7 @@ struct WsLayout {
 /* The integers the per-env LDS layout and the loop bounds of the kernels depend on. */
 struct VnlDims {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
-  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton, blk_cfg;
+  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton, blk_cfg, path_runs;
 };
 
 /* The LDS layout as a function of the dims: evaluated by the host at env creation and, for a model the kernels are
@@ -188,7 +189,7 @@ struct VnlSpecGeneric {
 struct VnlSpecRodent {
   static constexpr bool fixed = true;
   static constexpr VnlDims D{74, 73, 30, 66, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 6, 36, 6 | (13 << 8), 0,
-                             3 | (3 << 4) | (3 << 8) | (4 << 12)};
+                             3 | (3 << 4) | (3 << 8) | (4 << 12), 2};
   static constexpr WsLayout L = vnl_make_layout(D);
 };
 
