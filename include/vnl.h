@@ -137,6 +137,10 @@ typedef struct vnl_dims {
   int32_t nq, nv, nu, nbody, njnt, ngeom_collide, ncon, nefc, obs_size, traj_size;
   int32_t workspace_floats_per_env; /* per-env LDS working set, in floats */
   int32_t workgroups_per_cu;        /* occupancy of the step kernel as reported by the HIP runtime */
+  int32_t nbody_dynamic;            /* bodies the dynamics works on: the model's welded (jointless) bodies are folded into their
+                                       parents; every one of the nbody bodies still has its row of xpos / xquat */
+  int32_t kernel_specialised;       /* 1: the env runs the kernels specialised at compile time for its dimensions (the reference's
+                                       rodent); 0: the generic kernels */
 } vnl_dims;
 
 const char* vnl_last_error(void);

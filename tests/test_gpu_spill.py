@@ -102,6 +102,9 @@ def test_specialised_kernels_equal_the_generic_kernels_bit_for_bit():
 
     path = hip_build.build(variant="nospec")
     B = 512
+    # the product runs the specialised kernels on the rodent (a mismatch of the compile-time constants would fall back to the
+    # generic ones silently), the regression build the generic ones
+    assert int(_env(4).dims.kernel_specialised) == 1 and int(_env(4, _lib.load_library(path)).dims.kernel_specialised) == 0
     rng = np.random.default_rng(44)
     sf = rng.integers(0, 235, B).astype(np.int32)
     noise = (1e-3 * rng.standard_normal((B, 74))).astype(np.float32)

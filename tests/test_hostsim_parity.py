@@ -146,3 +146,31 @@ def test_multi_clip_container_selects_per_env_clip():
     assert np.allclose(d, shift, atol=1e-7)
     # a pure translation of body + reference leaves the egocentric features unchanged
     assert torch.allclose(st.info["traj"][0, 75:75 + 270], st.info["traj"][1, 75:75 + 270], atol=1e-6)
+
+
+def test_welded_bodies_are_folded_into_their_parents_and_keep_their_poses():
+    """The rodent's 13 jointless bodies move rigidly with their parents; the library folds them into those for the dynamics
+    (csrc/vnl_lib.hip: fuse_welded_bodies -- merged mass / centre of mass / inertia, re-attached children and collision geoms)
+    and still reports every body's pose.  The oracle works on the model as given: after two control steps the float64 host
+    build must agree with it on ALL 66 rows of xpos, and in particular on the rows of the welded bodies."""
+    B = 8
+    env = H.hostsim_env(B, "double")
+    m = env.sys
+    nb = int(m.scalars["nbody"])
+    assert int(env.dims.nbody) == nb == 66 and int(env.dims.nbody_dynamic) == 53
+    welded = [b for b in range(2, nb) if int(m.arrays["body_jntnum"][b]) == 0]
+    assert len(welded) == nb - int(env.dims.nbody_dynamic) == 13
+    sf, noise, acts = _inputs(B)
+    st = env.reset(start_frame=torch.from_numpy(sf), noise=torch.from_numpy(noise))
+    o = H.make_oracle(env, "f64")
+    ost = o.env_reset(sf, noise)
+    for k in range(2):
+        st = env.step(st, torch.from_numpy(acts[k]))
+        o.env_step(ost, acts[k])
+    xp = st.pipeline_state.xpos.numpy().reshape(B, nb, 3)
+    ox = ost["xpos"].reshape(B, nb, 3)
+    assert np.abs(xp - ox).max() < 1e-8  # (two control steps of chaotic amplification of ~1e-15)
+    assert np.abs(xp[:, welded] - ox[:, welded]).max() < 1e-8
+    # a welded body really is offset from its parent (the rows are not copies of the parents' rows)
+    par = np.asarray(m.arrays["body_parentid"])[welded]
+    assert np.abs(xp[:, welded] - xp[:, par]).max() > 1e-3

@@ -64,7 +64,8 @@ class StatePtrs(C.Structure):
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "nbody", "njnt", "ngeom_collide", "ncon", "nefc",
-                                          "obs_size", "traj_size", "workspace_floats_per_env", "workgroups_per_cu")]
+                                          "obs_size", "traj_size", "workspace_floats_per_env", "workgroups_per_cu",
+                                          "nbody_dynamic", "kernel_specialised")]
 
 
 class PolicySpec(C.Structure):

@@ -288,8 +288,9 @@ struct EnvWaveT {
   }
 
   // xpos / xquat / qfrc_actuator live in their (caller-owned, L2-resident) state buffers, not in LDS
-  VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * MI(nbody); }
-  VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * MI(nbody); }
+  // (rows of xpos / xquat: the bodies of the model AS GIVEN -- welded bodies included; the dynamics' body b is row m.body_out[b])
+  VNL_HD vreal* gxpos() const { return st.xpos + (size_t)e * 3 * MI(nbody_out); }
+  VNL_HD vreal* gxquat() const { return st.xquat + (size_t)e * 4 * MI(nbody_out); }
   VNL_HD vreal* gqfrc_act() const { return st.qfrc_actuator + (size_t)e * MI(nv); }
   // library-owned global scratch of this env: the second inverse factor of a substep (invert_aba) and its reciprocal pivots (factor_aba), nM + nv elements
   VNL_HD vreal* fac2() const { return ev.fac2 + (size_t)e * (MI(nM) + MI(nv)); }
@@ -480,11 +481,16 @@ struct EnvWaveT {
     }
     vreal* gx = gxpos();
     vreal* gq = gxquat();
-    VNL_FOR(b, MI(nbody)) {
+    VNL_FOR(ob, MI(nbody_out)) {  // every body of the model as given: its dynamic body's pose, composed with its fixed transform
+      const int b = m.out_dyn[ob];
       V3 p = ld3(src + 7 * b);
       Q4 q = ld4(src + 7 * b + 3);
-      gx[3 * b] = p.x, gx[3 * b + 1] = p.y, gx[3 * b + 2] = p.z;
-      gq[4 * b] = q.w, gq[4 * b + 1] = q.x, gq[4 * b + 2] = q.y, gq[4 * b + 3] = q.z;
+      if (MI(nbody_out) != MI(nbody)) {  // (some bodies are welded: identity transforms for the others)
+        p = p + qrot(t3(m.out_pos, ob), q);
+        q = qmul(q, t4(m.out_quat, ob));
+      }
+      gx[3 * ob] = p.x, gx[3 * ob + 1] = p.y, gx[3 * ob + 2] = p.z;
+      gq[4 * ob] = q.w, gq[4 * ob + 1] = q.x, gq[4 * ob + 2] = q.y, gq[4 * ob + 3] = q.z;
     }
     V3 O = ref_point();
     // cdof: the hinges (every joint but a free root's) ..
@@ -528,9 +534,10 @@ struct EnvWaveT {
         for (int k = 0; k < 10; k++) s[o + k] = vreal(0.);
         continue;
       }
-      M3 R = qmat(gquat4(b));
+      const int ob = m.body_out[b];
+      M3 R = qmat(gquat4(ob));
       vreal mass = m.body_mass[b];
-      V3 xip = gpos3(b) + mmul(R, t3(m.body_ipos, b));
+      V3 xip = gpos3(ob) + mmul(R, t3(m.body_ipos, b));
       csum = csum + xip * mass;
       V3 r = xip - O;
       const vreal* I6 = m.body_inertia6 + 6 * b;  // xx yy zz xy xz yz (body axes, about ipos)
@@ -1110,6 +1117,12 @@ struct EnvWaveT {
   }
 
   VNL_HD int vstore() const { return (LO(P) + 3) & ~3; }  // [nv][(V1, V2) x 6]: over crb, below cvel (factor_pair_ok)
+  // where bias_forces leaves cvel for make_constraint: behind cacc / cfrc (pool + 16 nbody) and, where the pool has the room,
+  // behind the store of the V vectors too (with the welded bodies folded away the body arrays are shorter than that store)
+  VNL_HD int cvel_at() const {
+    const int a = LO(P) + 16 * MI(nbody), b = vstore() + 12 * MI(nv);
+    return (b > a && b + 6 * MI(nbody) <= LO(smooth)) ? b : a;
+  }
 
   // Both inverse factors N = L^-1 from the same 6-vectors: walking up from row k, with C = V_k at the start,
   //     N(k, j) = -cdof_j . C,     C += N(k, j) V_j          for the parent j, the grandparent, ..
@@ -1171,7 +1184,7 @@ struct EnvWaveT {
   VNL_HD bool factor_pair_ok() const {
     const int nv = MI(nv);
     if (!MI(eulerdamp) || !m.fac_match) return false;
-    return nv <= VNL_ROWSETS_2 * VNL_LANES && 12 * nv + 3 <= 16 * MI(nbody) && VNL_FAC_LINES * 16 + 3 <= 6 * nv;
+    return nv <= VNL_ROWSETS_2 * VNL_LANES && vstore() + 12 * nv <= cvel_at() && VNL_FAC_LINES * 16 + 3 <= 6 * nv;
   }
   VNL_HD void factor_both(vreal h) const {
     if (MI(nv) <= VNL_ROWSETS_1 * VNL_LANES) factor_aba<VNL_ROWSETS_1>(h);
@@ -1435,11 +1448,11 @@ struct EnvWaveT {
   // make_constraint).  Needs cinert in T1.
   VNL_HD int bias_forces() const {
     int nb6 = 6 * MI(nbody);
-    int X0 = LO(P) + 10 * MI(nbody), X1 = X0 + nb6;  // after cinert; cvel has to end in X1 (X0 is reused)
+    int X0 = LO(P) + 10 * MI(nbody);  // after cinert: cacc, then cfrc in place
     // cvel[b] = sum of cdof_d qvel_d over the dofs on b's path: differences of the dof prefix sums (parked in the
     // factor buffer, which is free until the mass matrix is built)
     dof_prefix(LO(qvel), LO(LD));
-    const int cv = X1;
+    const int cv = cvel_at();
     VNL_FOR(b, MI(nbody)) st6(cv + 6 * b, path_sum(LO(LD), m.body_pathseg + 8 * b));
     VNL_SYNC();
     VNL_PROF(2);
@@ -1595,8 +1608,9 @@ struct EnvWaveT {
     }
     VNL_FOR(g, MI(ncg)) {
       int bd = m.cg_body[g], c0 = m.cg_conadr[g], type = m.cg_type[g];
-      Q4 bq = gquat4(bd);
-      V3 gpos = gpos3(bd) + qrot(t3(m.cg_pos, g), bq);
+      const int obd = m.body_out[bd];
+      Q4 bq = gquat4(obd);
+      V3 gpos = gpos3(obd) + qrot(t3(m.cg_pos, g), bq);
       M3 R = qmat(qmul(bq, t4(m.cg_quat, g)));
       V3 size = t3(m.cg_size, g);
       vreal dist0 = vreal(0.), dist1 = vreal(0.);
@@ -2587,7 +2601,7 @@ struct EnvWaveT {
     load_tables();
     load_state();
     // rtrunk from the OLD pipeline state and OLD frame (rodent.py:250-262, 296)
-    vreal rtrunk = termination(clip, old_frame, s + LO(qpos), st.xpos + (size_t)e * 3 * MI(nbody));
+    vreal rtrunk = termination(clip, old_frame, s + LO(qpos), gxpos());
     const vreal* ac = action + (size_t)e * MI(nu);
     VNL_FOR(i, MI(nu)) {
       vreal c = ac[i];

@@ -147,8 +147,165 @@ static int upload_raw(vnl_env* env, const T* src, size_t n, const T** dst) {
   return upload<T, T>(env, tmp, dst);
 }
 
+// ---- welded bodies -------------------------------------------------------------------------------------------------
+// A body without joints moves rigidly with its parent: for the dynamics it IS part of the parent.  The rodent has 13 such
+// bodies among its 66, which is what pushed every per-body loop of the step kernel over the 64 lanes of a wave.  The model
+// handed to the kernels therefore has them folded into their parents -- mass, centre of mass and inertia merged exactly
+// (parallel-axis theorem in the parent's frame), children and collision geoms re-attached with composed fixed transforms --
+// while every body of the model AS GIVEN keeps its row of xpos / xquat (pose of its dynamic body composed with its fixed
+// transform).  The oracle works on the model as given: the parity tests check this transformation with everything else.
+struct FuseMap {
+  int nb_out = 0;
+  std::vector<int> out_dyn, body_out;
+  std::vector<double> out_pos, out_quat;
+};
+static void qmul_d(const double* a, const double* b, double* o) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+static void qmat_d(const double* q, double* R) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z), R[1] = 2 * (x * y - w * z), R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z), R[4] = 1 - 2 * (x * x + z * z), R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y), R[7] = 2 * (y * z + w * x), R[8] = 1 - 2 * (x * x + y * y);
+}
+static void mulv_d(const double* R, const double* v, double* o) {
+  for (int r = 0; r < 3; r++) o[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+}
+static bool fuse_welded_bodies(const vnl_model& in, vnl_model* out, FuseMap* fm) {
+  const int nb = (int)in.scalar("nbody");
+  const auto& bp = in.i.at("body_parentid");
+  const auto& jn = in.i.at("body_jntnum");
+  std::vector<char> keep(nb, 1);
+  int nd = 0;
+  for (int b = 0; b < nb; b++) {
+    keep[b] = (b < 2 || jn[b] > 0) ? 1 : 0;
+    nd += keep[b];
+  }
+  fm->nb_out = nb;
+  fm->out_dyn.assign(nb, 0), fm->out_pos.assign(3 * (size_t)nb, 0.0), fm->out_quat.assign(4 * (size_t)nb, 0.0);
+  fm->body_out.clear();
+  const auto& bpos = in.f.at("body_pos");
+  const auto& bquat = in.f.at("body_quat");
+  for (int b = 0, k = 0; b < nb; b++) {  // fixed transform of every body in the frame of the dynamic body it rides on
+    double* fp = &fm->out_pos[3 * (size_t)b];
+    double* fq = &fm->out_quat[4 * (size_t)b];
+    if (keep[b]) {
+      fm->out_dyn[b] = k++, fm->body_out.push_back(b);
+      fq[0] = 1.0;
+    } else {
+      const int p = bp[b];
+      fm->out_dyn[b] = fm->out_dyn[p];
+      double R[9], t[3];
+      qmat_d(&fm->out_quat[4 * (size_t)p], R), mulv_d(R, &bpos[3 * (size_t)b], t);
+      for (int c = 0; c < 3; c++) fp[c] = fm->out_pos[3 * (size_t)p + c] + t[c];
+      qmul_d(&fm->out_quat[4 * (size_t)p], &bquat[4 * (size_t)b], fq);
+    }
+  }
+  if (nd == nb) return false;
+  *out = in;
+  out->f["nbody"] = {(double)nd};
+  auto pick_i = [&](const char* k) {
+    std::vector<int> v;
+    for (int b = 0; b < nb; b++)
+      if (keep[b]) v.push_back(in.i.at(k)[b]);
+    out->i[k] = v;
+  };
+  auto pick_f = [&](const char* k, int w) {
+    std::vector<double> v;
+    for (int b = 0; b < nb; b++)
+      if (keep[b]) v.insert(v.end(), in.f.at(k).begin() + (size_t)w * b, in.f.at(k).begin() + (size_t)w * (b + 1));
+    out->f[k] = v;
+  };
+  pick_i("body_jntadr"), pick_i("body_jntnum"), pick_i("body_rootid"), pick_i("body_dofadr"), pick_i("body_dofnum");
+  pick_f("body_invweight0", 2);
+  std::vector<int> par;
+  std::vector<double> pos, quat;
+  for (int b = 0; b < nb; b++) {
+    if (!keep[b]) continue;
+    const int p = b > 0 ? bp[b] : 0;
+    par.push_back(fm->out_dyn[p]);
+    double R[9], t[3], q[4];
+    qmat_d(&fm->out_quat[4 * (size_t)p], R), mulv_d(R, &bpos[3 * (size_t)b], t);
+    for (int c = 0; c < 3; c++) pos.push_back(fm->out_pos[3 * (size_t)p + c] + t[c]);
+    qmul_d(&fm->out_quat[4 * (size_t)p], &bquat[4 * (size_t)b], q);
+    quat.insert(quat.end(), q, q + 4);
+  }
+  out->i["body_parentid"] = par, out->f["body_pos"] = pos, out->f["body_quat"] = quat;
+  // mass / centre of mass / inertia of every dynamic body with what is welded to it: moments about the body's origin, in its axes
+  std::vector<double> M(nd, 0.0), mc(3 * (size_t)nd, 0.0), J(9 * (size_t)nd, 0.0);
+  const auto& mass = in.f.at("body_mass");
+  const auto& ipos = in.f.at("body_ipos");
+  const auto& ifull = in.f.at("body_inertia_full");
+  for (int b = 0; b < nb; b++) {
+    const int dyn = fm->out_dyn[b];
+    double R[9], c[3], t[3];
+    qmat_d(&fm->out_quat[4 * (size_t)b], R), mulv_d(R, &ipos[3 * (size_t)b], t);
+    for (int k = 0; k < 3; k++) c[k] = fm->out_pos[3 * (size_t)b + k] + t[k];
+    const double m = mass[b], cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    M[dyn] += m;
+    for (int k = 0; k < 3; k++) mc[3 * (size_t)dyn + k] += m * c[k];
+    const double* I = &ifull[9 * (size_t)b];
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) {
+        double v = 0;  // (R I R')(r, q)
+        for (int a = 0; a < 3; a++)
+          for (int e = 0; e < 3; e++) v += R[3 * r + a] * I[3 * a + e] * R[3 * q + e];
+        J[9 * (size_t)dyn + 3 * r + q] += v + m * ((r == q ? cc : 0.0) - c[r] * c[q]);
+      }
+  }
+  std::vector<double> nip(3 * (size_t)nd, 0.0), nI(9 * (size_t)nd, 0.0);
+  for (int dyn = 0; dyn < nd; dyn++) {
+    double c[3] = {0, 0, 0};
+    if (M[dyn] > 0)
+      for (int k = 0; k < 3; k++) c[k] = mc[3 * (size_t)dyn + k] / M[dyn];
+    else
+      for (int k = 0; k < 3; k++) c[k] = ipos[3 * (size_t)fm->body_out[dyn] + k];
+    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    for (int k = 0; k < 3; k++) nip[3 * (size_t)dyn + k] = c[k];
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) nI[9 * (size_t)dyn + 3 * r + q] = J[9 * (size_t)dyn + 3 * r + q] - M[dyn] * ((r == q ? cc : 0.0) - c[r] * c[q]);
+  }
+  out->f["body_mass"] = M, out->f["body_ipos"] = nip, out->f["body_inertia_full"] = nI;
+  for (const char* k : {"jnt_bodyid", "dof_bodyid"}) {
+    std::vector<int> v = in.i.at(k);
+    for (int& x : v) x = fm->out_dyn[x];
+    out->i[k] = v;
+  }
+  {  // collision geoms: onto the dynamic body, frames composed; the contact's inverse weight stays that of the body as given
+    const auto& gb = in.i.at("cg_bodyid");
+    const auto& gp = in.f.at("cg_pos");
+    const auto& gq = in.f.at("cg_quat");
+    const auto& iw0 = in.f.at("body_invweight0");
+    std::vector<int> nb_(gb.size());
+    std::vector<double> np = gp, nq = gq, giw(gb.size());
+    for (size_t g = 0; g < gb.size(); g++) {
+      const int ob = gb[g];
+      nb_[g] = fm->out_dyn[ob], giw[g] = iw0[2 * (size_t)ob];
+      double R[9], t[3];
+      qmat_d(&fm->out_quat[4 * (size_t)ob], R), mulv_d(R, &gp[3 * g], t);
+      for (int c = 0; c < 3; c++) np[3 * g + c] = fm->out_pos[3 * (size_t)ob + c] + t[c];
+      qmul_d(&fm->out_quat[4 * (size_t)ob], &gq[4 * g], &nq[4 * g]);
+    }
+    out->i["cg_bodyid"] = nb_, out->f["cg_pos"] = np, out->f["cg_quat"] = nq, out->f["cg_body_invweight0"] = giw;
+  }
+  return true;
+}
+
 static int build_dev_model(vnl_env* env, const vnl_model* hm) {
   DevModel& d = env->dm;
+  vnl_model fused;
+  FuseMap fmap;
+  for (const char* k : {"body_parentid", "body_jntnum"})
+    if (hm->i.find(k) == hm->i.end()) return fail(VNL_ERR_BLOB, "blob section %s missing", k);
+  for (const char* k : {"body_pos", "body_quat", "body_ipos", "body_inertia_full", "body_mass", "body_invweight0", "cg_pos", "cg_quat"})
+    if (hm->f.find(k) == hm->f.end()) return fail(VNL_ERR_BLOB, "blob section %s missing", k);
+  for (const char* k : {"jnt_bodyid", "dof_bodyid", "cg_bodyid", "body_jntadr", "body_rootid", "body_dofadr", "body_dofnum"})
+    if (hm->i.find(k) == hm->i.end()) return fail(VNL_ERR_BLOB, "blob section %s missing", k);
+  if (fuse_welded_bodies(*hm, &fused, &fmap)) hm = &fused;
+  d.nbody_out = fmap.nb_out;
   auto S = [&](const char* k) { return hm->scalar(k); };
   d.nq = (int)S("nq"), d.nv = (int)S("nv"), d.nu = (int)S("nu"), d.nbody = (int)S("nbody"), d.njnt = (int)S("njnt");
   d.ncg = (int)S("ncg"), d.ncon = (int)S("ncon"), d.nlimit = (int)S("nlimit"), d.nefc = (int)S("nefc");
@@ -222,6 +379,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
 #define UPF(name, vec) if ((rc = upload<vreal, double>(env, vec, &d.name)) != VNL_OK) return rc;
 #define UPI(name, vec) if ((rc = upload<int, int>(env, vec, &d.name)) != VNL_OK) return rc;
   UPI(body_parent, I("body_parentid")) UPI(body_jntadr, I("body_jntadr")) UPI(body_jntnum, I("body_jntnum"))
+  UPI(out_dyn, fmap.out_dyn) UPI(body_out, fmap.body_out) UPF(out_pos, fmap.out_pos) UPF(out_quat, fmap.out_quat)
   {
     std::vector<int> da(nb, 0), dn(nb, 0);
     for (int b = 0; b < nb; b++) {
@@ -563,7 +721,8 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
     double impratio = S("impratio");
     for (int g = 0; g < ng; g++) {
       mu[g] = F("cg_friction")[3 * g];
-      double t = F("body_invweight0")[0] + F("body_invweight0")[2 * (size_t)I("cg_bodyid")[g]];
+      double t = F("body_invweight0")[0] + (hm->f.count("cg_body_invweight0") ? F("cg_body_invweight0")[g]
+                                                                                : F("body_invweight0")[2 * (size_t)I("cg_bodyid")[g]]);
       iw[g] = (t + mu[g] * mu[g] * t) * 2 * mu[g] * mu[g] / impratio;  // constraint._instantiate_contact
     }
     UPF(cg_mu, mu) UPF(cg_invweight, iw)
@@ -575,7 +734,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
 
 static VnlDims dims_of(const DevModel& d) {
   return VnlDims{d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ncg, d.ncon, d.nlimit, d.nefc, d.nM, d.iterations, d.ls_iterations, d.eulerdamp,
-                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton, d.blk_cfg, d.path_runs};
+                 d.root_free, d.max_depth, d.jump_rounds, d.fac_steps, d.fac_nleaf, d.solver_newton, d.blk_cfg, d.path_runs, d.nbody_out};
 }
 
 static void layout(vnl_env* env) {
@@ -656,10 +815,10 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
   e.traj_size = e.ref_len * (3 * e.napp + 6 * e.nb + 3 + e.njc);
   bool ok = e.T >= e.ref_len && e.C >= 1 && e.nb >= 1 && e.com_ref_col >= 0 && e.com_ref_col < e.nb && d.nq >= 7 &&
             d.root_free;
-  for (int k = 0; ok && k < e.nb; k++) ok = es->body_idxs[k] >= 0 && es->body_idxs[k] < d.nbody;
-  for (int k = 0; ok && k < e.nee; k++) ok = es->end_eff_idx[k] >= 0 && es->end_eff_idx[k] < d.nbody;
+  for (int k = 0; ok && k < e.nb; k++) ok = es->body_idxs[k] >= 0 && es->body_idxs[k] < d.nbody_out;
+  for (int k = 0; ok && k < e.nee; k++) ok = es->end_eff_idx[k] >= 0 && es->end_eff_idx[k] < d.nbody_out;
   for (int k = 0; ok && k < e.napp; k++)
-    ok = es->app_body[k] >= 0 && es->app_body[k] < d.nbody && es->app_ref_col[k] >= 0 && es->app_ref_col[k] < e.nb;
+    ok = es->app_body[k] >= 0 && es->app_body[k] < d.nbody_out && es->app_ref_col[k] >= 0 && es->app_ref_col[k] < e.nb;
   for (int k = 0; ok && k < e.njc; k++) ok = es->joint_cols[k] >= 0 && es->joint_cols[k] < d.nq - 7;
   if (!ok) {
     vnl_env_destroy(env);
@@ -740,10 +899,11 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
 extern "C" int vnl_env_dims(const vnl_env* env, vnl_dims* o) {
   if (!env || !o) return fail(VNL_ERR_ARG, "vnl_env_dims: null argument");
   const DevModel& d = env->dm;
-  o->nq = d.nq, o->nv = d.nv, o->nu = d.nu, o->nbody = d.nbody, o->njnt = d.njnt, o->ngeom_collide = d.ncg;
+  o->nq = d.nq, o->nv = d.nv, o->nu = d.nu, o->nbody = d.nbody_out, o->njnt = d.njnt, o->ngeom_collide = d.ncg;
   o->ncon = d.ncon, o->nefc = d.nefc, o->obs_size = env->de.obs_size, o->traj_size = env->de.traj_size;
   o->workspace_floats_per_env = env->L.total;
   o->workgroups_per_cu = env->blocks_per_cu;
+  o->nbody_dynamic = d.nbody, o->kernel_specialised = env->spec;
   return VNL_OK;
 }
 

@@ -38,6 +38,7 @@ struct DevModel {
   int fac_steps; /* number of steps of the factorisation schedule */
   int fac_nleaf; /* low byte: leaf dofs of the tree if <= VNL_FAC_LINES (factor_rows can then carry and solve a right-hand
                     side), else 0; bits 8..: depth of the deepest of the rows 64 .. (second lane set) */
+  int nbody_out; /* bodies of the model as given (rows of xpos / xquat): nbody counts the DYNAMIC bodies, welded ones folded into their parents */
   int path_runs; /* most runs of consecutive dofs / ancestor bodies any body's path has (<= 4): EnvWave::path_sum walks that many */
   int blk_cfg;   /* EnvWave::blk_apply: trips of the row form | trips of the column form << 4 | combine steps (row) << 8 | (column) << 12; 0 = no table */
   int dbg_stage, dbg_count; /* timing knob, see EnvWave::forward */
@@ -53,6 +54,11 @@ struct DevModel {
                                         consecutive ancestor bodies (incl. the body): begin | end << 8 (0 = none) */
   const unsigned char* jump; /* [jump_rounds][nbody]: 2^r-th ancestor body, 0 = none */
   const vreal *body_pos, *body_quat, *body_ipos, *body_inertia6, *body_mass;
+  // welded (jointless) bodies are folded into their parents for the dynamics (vnl_lib.hip: fuse_welded_bodies); every body of
+  // the model as given still gets its pose: out_dyn[ob] = the dynamic body it rides on, (out_pos, out_quat)[ob] = its fixed
+  // transform in that body's frame (identity for a dynamic body); body_out[b] = the given model's index of dynamic body b
+  const int *out_dyn, *body_out;
+  const vreal *out_pos, *out_quat;
   // joints
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_body;
   const vreal *jnt_pos, *jnt_axis, *jnt_qpos0, *jnt_stiffness, *jnt_springref;
@@ -121,7 +127,7 @@ struct WsLayout {
 /* The integers the per-env LDS layout and the loop bounds of the kernels depend on. */
 struct VnlDims {
   int nq, nv, nu, nbody, njnt, ncg, ncon, nlimit, nefc, nM;
-  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton, blk_cfg, path_runs;
+  int iterations, ls_iterations, eulerdamp, root_free, max_depth, jump_rounds, fac_steps, fac_nleaf, solver_newton, blk_cfg, path_runs, nbody_out;
 };
 
 /* The LDS layout as a function of the dims: evaluated by the host at env creation and, for a model the kernels are
@@ -188,8 +194,9 @@ struct VnlSpecGeneric {
 /* the reference's rodent (assets/rodent.xml as envs/rodent.py:39-63 compiles it), CG 6 / 6 */
 struct VnlSpecRodent {
   static constexpr bool fixed = true;
-  static constexpr VnlDims D{74, 73, 30, 66, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 6, 36, 6 | (13 << 8), 0,
-                             3 | (3 << 4) | (3 << 8) | (4 << 12), 2};
+  // (53 dynamic bodies: 13 of the model's 66 are welded to their parents and folded into them, vnl_lib.hip: fuse_welded_bodies)
+  static constexpr VnlDims D{74, 73, 30, 53, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 5, 36, 6 | (13 << 8), 0,
+                             3 | (3 << 4) | (3 << 8) | (4 << 12), 2, 66};
   static constexpr WsLayout L = vnl_make_layout(D);
 };
 
