@@ -43,7 +43,6 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_LANES 1
 #define VNL_ROWS_PER_LANE 512
 #define VNL_ROWS_SMALL 320
-#define VNL_PREFIX_PER_LANE 512
 #define VNL_CHAIN_WIDTH 8
 #define VNL_ROWSETS_1 64
 #define VNL_POST_THREADS 1

@@ -42,7 +42,6 @@
 #define VNL_LANES 64
 #define VNL_ROWS_PER_LANE 8 /* constraint rows a lane keeps in registers during a line search: nefc <= 512 */
 #define VNL_ROWS_SMALL 5    /* specialisation for nefc <= 320 (the rodent has 303) */
-#define VNL_PREFIX_PER_LANE 8 /* 6 * nbody <= 512 elements per in-place tree prefix */
 #define VNL_CHAIN_WIDTH 8 /* entries of a sparse row / column fetched per trip of row_dot / col_apply */
 #define VNL_ROWSETS_1 1 /* matrix rows a lane keeps in registers while factorising: nv <= 64 .. */
 #define VNL_ROWSETS_2 2 /* .. or nv <= 128 */
@@ -363,44 +362,6 @@ struct EnvWaveT {
   }
 
   // ------------------------------------------------------------------ kinematics
-  // Tree prefix by pointer jumping: on entry buf0[6b+k] holds each body's own contribution; on exit
-  // the returned buffer holds the sum over the body's whole ancestor path.  jump_r[b] = 2^r-th
-  // ancestor (0 = none), log2(depth) rounds, ping-pong between buf0 and buf1.
-  VNL_HD int tree_prefix(int buf0, int buf1) const {
-    int src = buf0, dst = buf1;
-    for (int r = 0; r < MI(jump_rounds); r++) {
-      VNL_FOR(i, 6 * MI(nbody)) {
-        int b = i / 6, j = jump_of(r, b);
-        vreal v = s[src + i];
-        if (j > 0) v += s[src + 6 * j + (i - 6 * b)];
-        s[dst + i] = v;
-      }
-      VNL_SYNC();
-      int t = src;
-      src = dst, dst = t;
-    }
-    return src;
-  }
-
-  // In-place variant (one buffer): every element first reads its own and its jump-ancestor's value
-  // into registers, then -- after a barrier -- writes the sum back.
-  VNL_HD void tree_prefix_inplace(int buf) const {
-    for (int r = 0; r < MI(jump_rounds); r++) {
-      vreal keep[VNL_PREFIX_PER_LANE];
-      int n = 6 * MI(nbody), q = 0;
-      VNL_FOR(i, n) {
-        int b = i / 6, j = jump_of(r, b);
-        vreal v = s[buf + i];
-        if (j > 0) v += s[buf + 6 * j + (i - 6 * b)];
-        keep[q++] = v;
-      }
-      VNL_SYNC();
-      q = 0;
-      VNL_FOR(i, n) s[buf + i] = keep[q++];
-      VNL_SYNC();
-    }
-  }
-
   // smooth.kinematics in three fork-join phases:
   //  (1) per body, in parallel: its transform relative to the parent frame as a function of its own
   //      joint angles (MJX's anchor / off-centre rotation rule applied in the parent frame), plus the

@@ -865,7 +865,7 @@ extern "C" int vnl_env_create(const vnl_model* hm, const vnl_envspec* es, int32_
 #endif
   if (6 * d.nbody > 512) {
     vnl_env_destroy(env);
-    return fail(VNL_ERR_UNSUPPORTED, "more than 85 bodies (in-place tree prefix keeps 8 elements per lane)");
+    return fail(VNL_ERR_UNSUPPORTED, "more than 85 dynamic bodies (the per-body scans of bias_forces keep 8 elements per lane)");
   }
   if (d.nu > d.nv) {
     vnl_env_destroy(env);
