@@ -1287,10 +1287,10 @@ struct EnvWaveT {
   }
 
   // The same two products, BALANCED: a lane per row (column) makes the wave wait for the deepest row (35 entries for the
-  // rodent, the mean is 14) and the largest subtree (72, same mean).  The host cuts every row / column into blocks of <= 8
-  // entries and deals the blocks out over the lanes (m.blk_tab, csrc/vnl_lib.hip); the blocks of one row sit in adjacent
+  // rodent, the mean is 14) and the largest subtree (72, same mean).  The host cuts every row / column into blocks of <= 13
+  // entries (VNL_BLK_W) and deals the blocks out over the lanes (m.blk_tab, csrc/vnl_lib.hip); the blocks of one row sit in adjacent
   // lanes of a 16-lane DPP row, their partial sums meet in the first of them by shifts (VNL_SEG_SUM) and that lane writes
-  // the element: 3 trips per product for the rodent instead of 5 (rows) and 10 (columns).
+  // the element: 2 trips of 13-entry blocks per product for the rodent instead of 5 (rows) and 10 (columns) of 8.
   //   COL == false: out[i] = in[i] + sum_t A(i, anc_t) in[anc_t]          COL == true: out[a] = in[a] + sum_{i in desc(a)} A(i, a) in[i]
   //   dmode: 0 none, 1 multiply by dinv, 2 divide by dinv
   template <int ST, bool COL>
@@ -1298,7 +1298,7 @@ struct EnvWaveT {
     const int cfg = MI(blk_cfg);
     const int trips = COL ? (cfg >> 4) & 15 : cfg & 15, steps = COL ? (cfg >> 12) & 15 : (cfg >> 8) & 15;
     const unsigned* tab = m.blk_tab + (COL ? (cfg & 15) * 64 : 0);
-    constexpr int W = 8, MAXT = 4;  // (the host builds no table that needs more trips)
+    constexpr int W = VNL_BLK_W, MAXT = 4;  // (the host builds no table that needs more trips)
 #ifdef __HIP_DEVICE_COMPILE__
     unsigned pre[MAXT];  // every trip's descriptor requested before the first is used: one exposed global-memory round trip per product
 #pragma unroll
@@ -1340,9 +1340,10 @@ struct EnvWaveT {
         }
         vreal p0 = vreal(0.), p1 = vreal(0.);
 #pragma unroll
-        for (int u = 0; u < W; u += 2) {
-          p0 += u < n ? l_[u] * x[u] : vreal(0.);
-          p1 += u + 1 < n ? l_[u + 1] * x[u + 1] : vreal(0.);
+        for (int u = 0; u < W; u++) {
+          const vreal pr = u < n ? l_[u] * x[u] : vreal(0.);
+          if (u & 1) p1 += pr;
+          else p0 += pr;
         }
         VNL_AT(part, l) = p0 + p1;
         VNL_AT(dsc, l) = d;

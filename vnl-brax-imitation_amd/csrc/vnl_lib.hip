@@ -619,7 +619,7 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
         std::vector<Item> items;
         int total = 0, longest = 1;
         for (int r = 0; r < nv; r++) {
-          const int len = colform ? ndesc[r] : depth[r], nb_ = len > 0 ? (len + 7) / 8 : 1;
+          const int len = colform ? ndesc[r] : depth[r], nb_ = len > 0 ? (len + VNL_BLK_W - 1) / VNL_BLK_W : 1;
           if (nb_ > 16) return false;
           items.push_back({r, nb_}), total += nb_, longest = nb_ > longest ? nb_ : longest;
         }
@@ -637,10 +637,10 @@ static int build_dev_model(vnl_env* env, const vnl_model* hm) {
             const int len = colform ? ndesc[it.r] : depth[it.r];
             for (int k = 0; k < it.nblk; k++) {
               const int slot = bin * 16 + fill[bin] + k, left = it.nblk - 1 - k;  // blocks of the row after this one
-              const int n = len - 8 * k > 8 ? 8 : (len - 8 * k > 0 ? len - 8 * k : 0);
+              const int n = len - VNL_BLK_W * k > VNL_BLK_W ? VNL_BLK_W : (len - VNL_BLK_W * k > 0 ? len - VNL_BLK_W * k : 0);
               unsigned payload;
-              if (colform) payload = (unsigned)(n > 0 ? it.r + 1 + 8 * k : it.r) | ((unsigned)depth[it.r] << 7);
-              else payload = (unsigned)(madr[it.r] + (n > 0 ? 1 + 8 * k : 0));
+              if (colform) payload = (unsigned)(n > 0 ? it.r + 1 + VNL_BLK_W * k : it.r) | ((unsigned)depth[it.r] << 7);
+              else payload = (unsigned)(madr[it.r] + (n > 0 ? 1 + VNL_BLK_W * k : 0));
               unsigned mask = 0;
               for (int b = 0; b < 4; b++)
                 if ((1 << b) <= left) mask |= 1u << b;

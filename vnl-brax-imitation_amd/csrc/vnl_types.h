@@ -29,6 +29,7 @@ typedef VNL_REAL vreal;
 #define VNL_TRACE_INTS (VNL_TRACE_ROWS + 16)
 
 #define VNL_LIVE_MAX 64 /* constraint rows kept in the compact list of existing rows (line search, one per lane) */
+#define VNL_BLK_W 13 /* entries per block of EnvWave::blk_apply: with 13 the rodent's rows (113 blocks) AND columns (127) fit two trips of 64 lanes */
 #define VNL_FAC_LINES 6 /* pivots per factorisation step (scratch lines in the dead CG vectors) */
 
 struct DevModel {
@@ -196,7 +197,7 @@ struct VnlSpecRodent {
   static constexpr bool fixed = true;
   // (53 dynamic bodies: 13 of the model's 66 are welded to their parents and folded into them, vnl_lib.hip: fuse_welded_bodies)
   static constexpr VnlDims D{74, 73, 30, 53, 68, 32, 59, 67, 303, 1119, 6, 6, 1, 1, 35, 5, 36, 6 | (13 << 8), 0,
-                             3 | (3 << 4) | (3 << 8) | (4 << 12), 2, 66};
+                             2 | (2 << 4) | (2 << 8) | (3 << 12), 2, 66};
   static constexpr WsLayout L = vnl_make_layout(D);
 };
 
