@@ -88,9 +88,9 @@ def test_humanoid_float64_build_matches_dense_oracle_and_reference_semantics():
         act = np.clip(0.4 * rng.standard_normal((B, 21)), -1, 1)
         st = env.step(st, torch.from_numpy(act))
         o.env_step(ost, act)
-            # (float64 on both sides: what is compared is ~1e-16 of rounding amplified by ~1e3 per substep over five substeps, so
-            # the bound only says "same algorithm"; the summation order of the M^-1 products moves the velocities between 8e-6 and
-            # 1.1e-5)
+        # (float64 on both sides: what is compared is ~1e-16 of rounding amplified by ~1e3 per substep over five substeps, so
+        # the bound only says "same algorithm"; the summation order of the M^-1 products moves the velocities between 8e-6 and
+        # 1.1e-5)
         assert H.scaled_err(ps.qpos.numpy(), ost["qpos"]) < 1e-6 and H.scaled_err(ps.qvel.numpy(), ost["qvel"]) < 3e-5
         m = np.stack([st.metrics[k].numpy() for k in st.metrics], 1)
         assert np.abs(m - ost["metrics"]).max() < 1e-9 and np.abs(st.reward.numpy() - ost["reward"]).max() < 1e-9  # (threshold 0.9 is a float32 in the ABI)
