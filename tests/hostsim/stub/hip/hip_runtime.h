@@ -60,6 +60,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
 #define VNL_SYNC_GLOBAL()
 #define VNL_LDS_DECL(name) static thread_local vreal name[32768]
 #define vnl_wave_sum(x) (x)
+#define vnl_wave_sum16(x) (x)
 #define vnl_wave_any(x) (x)
 #define VNL_SCAN_ADD(x, run) (run += (x), x = run)
 #define VNL_WAVE_ITEMS(n) (n)

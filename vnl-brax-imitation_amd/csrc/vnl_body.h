@@ -77,6 +77,17 @@ VNL_HD float vnl_wave_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));  // row_bcast:31
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
+// .. of values that are zero outside the first 16 lanes (the line search when at most 16 constraint rows exist, one per lane): the
+// butterfly inside the first row of 16 is the whole sum -- 4 DPP adds + 1 v_readlane
+VNL_HD float vnl_wave_sum16(float x) {
+#define VNL_DPP_STEP(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  VNL_DPP_STEP(0xB1);   // quad_perm [1,0,3,2]
+  VNL_DPP_STEP(0x4E);   // quad_perm [2,3,0,1]
+  VNL_DPP_STEP(0x141);  // row_half_mirror
+  VNL_DPP_STEP(0x140);  // row_mirror
+#undef VNL_DPP_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+}
 VNL_HD bool vnl_wave_any(bool x) { return __ballot(x) != 0ull; }
 // inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row
 // totals are carried over with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
@@ -1844,7 +1855,7 @@ struct EnvWaveT {
     }
   }
   template <int N, int RPL>
-  VNL_HD void ls_eval(const LsRows<RPL>& R, const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out) const {
+  VNL_HD void ls_eval(const LsRows<RPL>& R, const vreal* alpha, vreal qg0, vreal qg1, vreal qg2, LsPoint* out, bool few = false) const {
     vreal q0[N], q1[N], q2[N];
     for (int i = 0; i < N; i++) q0[i] = vreal(0.), q1[i] = vreal(0.), q2[i] = vreal(0.);
 #pragma unroll
@@ -1854,8 +1865,14 @@ struct EnvWaveT {
         q0[i] += act ? R.a0[j] : vreal(0.), q1[i] += act ? R.a1[j] : vreal(0.), q2[i] += act ? R.a2[j] : vreal(0.);
       }
     }
+    // (few: every row sits in one of the first 16 lanes -- the usual case, a dozen live rows: the short reduction)
+    if (few) {
+      for (int i = 0; i < N; i++) q0[i] = vnl_wave_sum16(q0[i]), q1[i] = vnl_wave_sum16(q1[i]), q2[i] = vnl_wave_sum16(q2[i]);
+    } else {
+      for (int i = 0; i < N; i++) q0[i] = vnl_wave_sum(q0[i]), q1[i] = vnl_wave_sum(q1[i]), q2[i] = vnl_wave_sum(q2[i]);
+    }
     for (int i = 0; i < N; i++) {
-      vreal t0 = qg0 + vnl_wave_sum(q0[i]), t1 = qg1 + vnl_wave_sum(q1[i]), t2 = qg2 + vnl_wave_sum(q2[i]);
+      vreal t0 = qg0 + q0[i], t1 = qg1 + q1[i], t2 = qg2 + q2[i];
       vreal a = alpha[i];
       out[i].alpha = a;
       out[i].cost = a * a * t2 + a * t1 + t0;
@@ -1870,14 +1887,15 @@ struct EnvWaveT {
       LsPoint p0, lo, hi;
       LsRows<RPL> rows;
       ls_load(rows, COMPACT);
+      const bool few = COMPACT && RPL == 1 && VNL_LANES >= 16 && num_live_rows() <= 16;
       vreal a1[1] = {vreal(0.)};
-      ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0);
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &p0, few);
       if (tr) {
         const int n0 = ls_count_active(rows, a1[0], COMPACT);
         VNL_SERIAL { tr[4] = n0, tr[24] = __builtin_bit_cast(int, (float)a1[0]); }
       }
       a1[0] = p0.alpha - p0.d0 / p0.d1;
-      ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo);
+      ls_eval<1>(rows, a1, gauss, qg1, qg2, &lo, few);
       if (tr) {
         const int n1 = ls_count_active(rows, a1[0], COMPACT);
         VNL_SERIAL { tr[5] = n1, tr[25] = __builtin_bit_cast(int, (float)a1[0]); }
@@ -1896,7 +1914,7 @@ struct EnvWaveT {
         if (!swap || (lo.d0 < vreal(0.) && lo.d0 > -gtol) || (hi.d0 > vreal(0.) && hi.d0 < gtol)) break;
         vreal a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, vreal(0.5) * (lo.alpha + hi.alpha)};
         LsPoint p[3];
-        ls_eval<3>(rows, a3, gauss, qg1, qg2, p);
+        ls_eval<3>(rows, a3, gauss, qg1, qg2, p, few);
         bool s1 = (lo.d0 > vreal(0.)) || (lo.d0 < p[0].d0);
         if (s1) lo = p[0];
         bool s2 = (p[2].d0 < vreal(0.)) && (lo.d0 < p[2].d0);
