@@ -1833,7 +1833,7 @@ struct EnvWaveT {
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool live = r < MI(nefc) && s[LO(efc_D) + (r < MI(nefc) ? r : 0)] != vreal(0.);
-      if (compact) live = (int)lane < num_live_rows();
+      if (compact) live = r < num_live_rows();
       n += VNL_COUNT(live && R.ja[j] + alpha * R.jv[j] < vreal(0.));
     }
     return n;
@@ -1844,9 +1844,9 @@ struct EnvWaveT {
     for (int j = 0; j < RPL; j++) {
       int r = (int)lane + j * VNL_LANES;
       bool ok = r < MI(nefc);
-      if (compact) {  // (RPL == 1) lane l takes the l-th existing row
-        ok = (int)lane < num_live_rows();
-        r = ok ? (int)live_rows()[lane] : 0;
+      if (compact) {  // lane l takes the l-th existing row (and the (l + 64)-th, RPL == 2)
+        ok = r < num_live_rows();
+        r = ok ? (int)live_rows()[r] : 0;
       }
       vreal D = ok ? fabs(s[LO(efc_D) + r]) : vreal(0.);
       vreal ja = ok ? s[LO(Jaref) + r] : vreal(0.), jv = ok ? s[LO(jv) + r] : vreal(0.);
@@ -2112,8 +2112,13 @@ struct EnvWaveT {
         VNL_SYNC();  // (the zero fill above is by all lanes, the entries by lane 0)
         VNL_SERIAL { trace[1] = it + 1; }
       }
-      vreal alpha = (num_live_rows() <= (VNL_LANES < VNL_LIVE_MAX ? VNL_LANES : VNL_LIVE_MAX))
+      // (rows that exist: typically a dozen to a few dozen of the 303 -- one per lane; along a free-running rollout a tenth of
+      // the envs has 65 .. 130 -- two per lane; only beyond that every row slot of the model is visited)
+      const int nlive = num_live_rows();
+      vreal alpha = (nlive <= (VNL_LANES < VNL_LIVE_MAX ? VNL_LANES : VNL_LIVE_MAX))
                         ? fresh().template line_search<1, true>(gauss, qg1, qg2, gtol, tr)
+                        : (nlive <= (2 * VNL_LANES < VNL_LIVE_MAX ? 2 * VNL_LANES : VNL_LIVE_MAX))
+                        ? fresh().template line_search<2, true>(gauss, qg1, qg2, gtol, tr)
                         : ((MI(nefc) <= 5 * VNL_LANES) ? fresh().template line_search<VNL_ROWS_SMALL>(gauss, qg1, qg2, gtol, tr)
                                                      : fresh().template line_search<VNL_ROWS_PER_LANE>(gauss, qg1, qg2, gtol, tr));
       VNL_FOR(d, nv) {

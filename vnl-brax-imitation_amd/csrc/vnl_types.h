@@ -28,7 +28,7 @@ typedef VNL_REAL vreal;
 #define VNL_TRACE_ROWS (8 + VNL_TRACE_REC * VNL_TRACE_ITERS) /* then 16 ints: bit r set = constraint row r present (D != 0) */
 #define VNL_TRACE_INTS (VNL_TRACE_ROWS + 16)
 
-#define VNL_LIVE_MAX 64 /* constraint rows kept in the compact list of existing rows (line search, one per lane) */
+#define VNL_LIVE_MAX 128 /* constraint rows kept in the compact list of existing rows (line search: one or two per lane) */
 #define VNL_BLK_W 13 /* entries per block of EnvWave::blk_apply: with 13 the rodent's rows (113 blocks) AND columns (127) fit two trips of 64 lanes */
 #define VNL_FAC_LINES 6 /* pivots per factorisation step (scratch lines in the dead CG vectors) */
 
