@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--eager", action="store_true", help="issue the unroll's launches from Python instead of replaying the "
                     "captured hipGraph (the round-2 form of the hot path)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` sub-record (full PPO training step)")
+    ap.add_argument("--no-train-secondary", action="store_true", help="skip `train_step.reference_proportions` (batch_size x num_minibatches = 8 x num_envs)")
     ap.add_argument("--train-steps", type=int, default=3, help="training steps timed for the `train_step` sub-record")
     ap.add_argument("--train-step-multi", action="store_true", help="also run the `train_step` leg with --gpus > 1 (RCCL "
                     "gradient all-reduce; off by default so that a collective problem cannot take the headline line down)")
@@ -143,11 +144,14 @@ def parity_compliance(env_cls, clip, kwargs, dev, num_envs: int = 512, seed: int
     return out
 
 
-def train_step_record(clip, kwargs, dev, B: int, world: int, steps: int) -> dict:
+def train_step_record(clip, kwargs, dev, B: int, world: int, steps: int, ratio: int = 1) -> dict:
     """Full PPO training step (BASELINE config 5, per-GPU share; reference ppo_imitation/train.py:293-394): 4096 envs,
     unroll 20, 32 minibatches x 16 updates of 128 trajectories, reference network sizes, the hand-written update inside
     the captured hipGraph.  Two epochs of `steps` training steps: the first contains the graph capture, the second is the
-    steady state whose `training/sps` (as the reference computes it) is reported."""
+    steady state whose `training/sps` (as the reference computes it) is reported.
+    `ratio`: batch_size x num_minibatches = ratio x num_envs -- 1 is SURVEY 8(d)'s primary config 5 (one unroll per training
+    step), 8 the reference's own proportions (configs/train_config.yaml:4-11: 32 x 32 / 128): eight unrolls per training
+    step, minibatches of 1024 trajectories."""
     import functools
 
     import torch
@@ -163,9 +167,9 @@ def train_step_record(clip, kwargs, dev, B: int, world: int, steps: int) -> dict
                            encoder_layer_sizes=c["encoder_layer_sizes"], decoder_layer_sizes=c["decoder_layer_sizes"])
     unroll, nmb, upd = c["unroll_length"], c["num_minibatches"], c["num_updates_per_batch"]
     log = []
-    ppo.train(environment=env, num_timesteps=2 * steps * B * world * unroll, episode_length=c["episode_length"],
+    ppo.train(environment=env, num_timesteps=2 * steps * ratio * B * world * unroll, episode_length=c["episode_length"],
               num_envs=B * world, learning_rate=c["learning_rate"], entropy_cost=c["entropy_cost"],
-              discounting=c["discounting"], unroll_length=unroll, batch_size=B * world // nmb, num_minibatches=nmb,
+              discounting=c["discounting"], unroll_length=unroll, batch_size=ratio * B * world // nmb, num_minibatches=nmb,
               num_updates_per_batch=upd, num_evals=3, normalize_observations=True, network_factory=nf, num_eval_envs=0,
               eval_env=None, kl_weight=c["kl_weight"], clipping_epsilon=c["clipping_epsilon"], update_backend="hip",
               progress_fn=lambda s_, m_: log.append((s_, dict(m_))))
@@ -174,11 +178,11 @@ def train_step_record(clip, kwargs, dev, B: int, world: int, steps: int) -> dict
         return {}
     m = log[-1][1]
     sps = float(m["training/sps"])
-    step_ms = B * world * unroll / sps * 1e3
+    step_ms = ratio * B * world * unroll / sps * 1e3
     return {"env_steps_per_s": sps, "ms_per_training_step": step_ms, "training_steps_timed": steps,
             "minibatch_steps_per_training_step": nmb * upd, "total_loss": float(m["training/total_loss"]),
             "config": f"rodent, {B} envs/GPU x {world} GPU, unroll {unroll}, {nmb} minibatches x {upd} updates of "
-                      f"{B // nmb} trajectories/GPU, intention net {c['encoder_layer_sizes']}/{c['intention_latent_size']}/"
+                      f"{ratio * B // nmb} trajectories/GPU ({ratio} unroll(s) per training step), intention net {c['encoder_layer_sizes']}/{c['intention_latent_size']}/"
                       f"{c['decoder_layer_sizes']}, value (1024, 1024), hand-written update in a captured hipGraph, "
                       "steady state (second epoch)"}
 
@@ -479,6 +483,13 @@ def main() -> None:
             train_rec = train_step_record(clip, H.env_kwargs(), dev, B, world, args.train_steps)
             if rank == 0 and world == 1:
                 train_rec.update(update_record(dev))
+            if world == 1 and not args.no_train_secondary:
+                # SURVEY 8(d) config 5 "secondary": the reference's own proportions, batch_size x num_minibatches = 8 x num_envs
+                torch.cuda.empty_cache()
+                try:
+                    train_rec["reference_proportions"] = train_step_record(clip, H.env_kwargs(), dev, B, world, 1, ratio=8)
+                except Exception as e:
+                    train_rec["reference_proportions"] = {"error": repr(e)}
         except Exception as e:
             if world > 1:
                 raise

@@ -243,3 +243,24 @@ def test_adam_kernel_matches_the_torch_update():
     assert int(sa["count"]) == int(sb["count"]) == 5
     assert torch.allclose(pa, pb, rtol=0, atol=2e-7) and torch.allclose(sa["nu"], sb["nu"], rtol=1e-6, atol=0)
     assert not torch.equal(pa, p0)
+
+
+def test_train_with_the_references_batch_proportions():
+    """configs/train_config.yaml:4-11 has batch_size x num_minibatches = 8 x num_envs (32 x 32 / 128): brax's training step then
+    collects EIGHT unrolls before its SGD epochs (reference ppo_imitation/train.py:293-330, `batch_size * num_minibatches //
+    num_envs` unrolls).  Same here, at a ratio of 2: every training step advances 2 x num_envs x unroll_length env steps, the
+    normaliser has seen them all, and the minibatches hold batch_size trajectories."""
+    env = H.hostsim_env(8)
+    nf = functools.partial(ppo_networks.make_intention_ppo_networks, intention_latent_size=16,
+                           encoder_layer_sizes=(32,), decoder_layer_sizes=(32,), value_hidden_layer_sizes=(32,))
+    log = []
+    _, params, metrics = ppo.train(
+        environment=env, num_timesteps=2 * 8 * 5 * 2, episode_length=150, num_envs=8, learning_rate=6e-4,
+        entropy_cost=1e-3, discounting=0.99, unroll_length=5, batch_size=4, num_minibatches=4,
+        num_updates_per_batch=2, num_evals=2, normalize_observations=True, network_factory=nf,
+        progress_fn=lambda s, m: log.append((s, m)), kl_weight=1e-4, clipping_epsilon=0.2, num_eval_envs=0, eval_env=None)
+    assert [s for s, _ in log][-1] == 160  # 2 training steps x (2 unrolls x 8 envs x 5 steps)
+    norm, flat = params
+    assert float(norm.count) == 160 and torch.isfinite(flat).all()
+    assert int(ppo.train.last_training_state.optimizer_state["count"]) == 2 * 2 * 4  # training steps x updates x minibatches
+    assert all(np.isfinite(float(metrics[k])) for k in ("training/total_loss", "training/v_loss", "training/policy_loss"))

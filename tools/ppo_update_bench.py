@@ -25,12 +25,13 @@ def main():
     ap.add_argument("--wg-target", type=int, default=0, help="workgroups a split-K weight gradient is split up to (default 256)")
     ap.add_argument("--fwd-mode", type=int, default=-1, help="the intention network's forward: 0 layer by layer, 1 one fused launch (csrc/vnl_policy.hip, training form), 2 first Dense as a GEMM + the rest fused (default)")
     ap.add_argument("--fused-threads", type=int, default=0, help="threads of the fused part of the forward (256 / 512 / 1024)")
+    ap.add_argument("--trajectories", type=int, default=128, help="trajectories per minibatch (128: batch_size x num_minibatches = num_envs; 1024: the reference's proportions, 8 x num_envs)")
     ap.add_argument("--noprio", action="store_true", help="no raised wave priority for the intention network's GEMMs")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses, running_statistics
     from vnl_brax_imitation_amd.ppo_imitation.intention_policy_network import LeafParams
 
-    cfg = dict(traj=795, obs=232, act=30, latent=64, enc=(256, 128), dec=(128, 256), val=(1024, 1024), T=20, B=128)
+    cfg = dict(traj=795, obs=232, act=30, latent=64, enc=(256, 128), dec=(128, 256), val=(1024, 1024), T=20, B=a.trajectories)
     nets, flat, data, norm, noise = _make(**cfg)
     dev = torch.device("cuda:0")
     to = lambda t: t.to(dev)  # noqa: E731

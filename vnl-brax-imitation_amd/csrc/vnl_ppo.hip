@@ -405,7 +405,9 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
     g.vecB = (lddz % 4 == 0) && (((uintptr_t)dZ) % 16 == 0);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int max_splits = K / 256 > 16 ? 16 : (K / 256 < 1 ? 1 : K / 256);  // slabs at least 256 deep
-    const bool big = pool->tile ? pool->tile == 128 : (in >= 512 && out >= 512);  // the one big weight gradient: 128 x 128 x 4 slabs
+    // the one big weight gradient: 128 x 128 tiles x 4 slabs at the reference's 2,560 rows; with many more rows (the reference's
+    // own proportions: 20,480) the 64 x 64 tile is the faster one again (3.01 vs 3.08 ms per minibatch step)
+    const bool big = pool->tile ? pool->tile == 128 : (in >= 512 && out >= 512 && rows <= 4096);
     const long tiles = big ? t128 : t64;
     int splits = 1;
     while (splits * 2 <= max_splits && tiles * splits < pool->wg_target) splits *= 2;
@@ -732,6 +734,7 @@ struct vnl_ppo_update {
                                 // null: the network is outside that kernel's limits -> layer by layer
   int fwd_mode = 2;  // the intention network's forward: 0 layer by layer, 1 ONE fused launch, 2 first Dense as a GEMM + the rest fused
                      // (tools/ppo_update_bench.py --fwd-mode; measured per minibatch step: see DESIGN section 5)
+  bool fwd_mode_forced = false;  // (tools/ppo_update_bench.py --fwd-mode: also beyond the row count the default route is used up to)
   int prio = 3;                 // wave priority of the intention network's GEMMs (tuning knob: tile = -2 switches it off)
 };
 
@@ -756,7 +759,7 @@ extern "C" void vnl_ppo_update_destroy(vnl_ppo_update* u) {
 // tuning knob of tools/ppo_update_bench.py (not part of include/vnl.h): force the GEMM tile (64 / 128; 0 = by shape)
 extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
   if (u && tile <= -10 && tile >= -12) {  // the intention network's forward: -10 layer by layer, -11 one fused launch, -12 GEMM + fused
-    u->fwd_mode = -10 - tile;
+    u->fwd_mode = -10 - tile, u->fwd_mode_forced = true;
     return VNL_OK;
   }
   if (u && (tile == -256 || tile == -512 || tile == -1024)) {  // threads of the fused part of the intention network's forward
@@ -1036,7 +1039,7 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
       const DenseP& d = u->val[nvl - 1];
       hipLaunchKernelGGL(rowdot_kernel, dim3((Nv + 3) / 4), dim3(256), 0, st, x, P + d.w, P + d.b, u->v, Nv, d.in);
     }
-    if (u->fused && u->fwd_mode != 0) {
+    if (u->fused && u->fwd_mode != 0 && (u->fwd_mode_forced || N <= 4096)) {  // (more rows: layer by layer is faster -- 20,480 rows: 3.08 vs 3.34 ms)
       // the whole intention network as ONE launch: a 16-row tile goes through encoder, latent heads, reparameterisation and
       // decoder without leaving LDS (csrc/vnl_policy.hip, the acting path's kernel in its training form), writing what
       // the backward pass reads; it takes the raw trajectory / observation, so it does not wait for prep_kernel
