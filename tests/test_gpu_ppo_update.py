@@ -43,7 +43,10 @@ HP = dict(entropy_cost=1e-3, discounting=0.99, reward_scaling=1.0, gae_lambda=0.
     dict(traj=45, obs=19, act=5, latent=6, enc=(40, 24), dec=(24, 40), val=(72, 56, 40), T=7, B=11,
          hp=dict(entropy_cost=0.05, discounting=0.9, reward_scaling=2.5, gae_lambda=0.8, clipping_epsilon=0.35,
                  normalize_advantage=False, kl_weight=0.3)),
-], ids=["reference-sizes", "small-odd", "other-coefficients"])
+    # a large minibatch with wide value layers: above 8,192 rows the wide layer's weight gradient takes its input transposed
+    # ([X | 1]' materialised by transpose_ones_kernel, then a plain product) and the forward goes layer by layer
+    dict(traj=45, obs=19, act=5, latent=6, enc=(40, 24), dec=(24, 40), val=(512, 512), T=20, B=420),
+], ids=["reference-sizes", "small-odd", "other-coefficients", "large-minibatch-wide-value"])
 def test_hip_update_matches_autograd_and_numpy(cfg):
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses
 
@@ -79,7 +82,10 @@ def test_hip_update_matches_autograd_and_numpy(cfg):
         ref = float(m_ref[k])
         assert abs(mt[i] - ref) <= 2e-5 * max(abs(ref), abs(float(m_ref["total_loss"]))), (k, mt[i], ref)
     # metrics[8]: mean of corrcoef([vs ; reward * scaling]) (intention_losses.py:186-188), float64 autograd path as reference
-    assert abs(mt[8] - float(m_ref["prediction_corr"])) < 2e-5, (mt[8], float(m_ref["prediction_corr"]))
+    # (NaN on BOTH sides = "not computed": the 2T x B rows of a large minibatch do not fit the one-workgroup kernel, and the
+    # torch path applies the same rule, intention_losses.py: _corr_fits)
+    pc_ref = float(m_ref["prediction_corr"])
+    assert (np.isnan(mt[8]) and np.isnan(pc_ref)) or abs(mt[8] - pc_ref) < 2e-5, (mt[8], pc_ref)
     # gradients per tensor, relative to that tensor's largest gradient entry
     worst = 0.0
     for lay, off0 in ((nets.policy_network.layout, 0), (nets.value_network.layout, n_pol)):
@@ -89,7 +95,8 @@ def test_hip_update_matches_autograd_and_numpy(cfg):
             scale = max(np.abs(b).max(), 1e-12)
             e = np.abs(a - b).max() / scale
             worst = max(worst, e)
-            assert e < 2e-5, (name, e, scale)
+            # (float32 sums over the T x B rows: the bound grows with the square root of the row count beyond the reference's 2,560)
+            assert e < 2e-5 * max(1.0, np.sqrt(T * B / 2560.0)), (name, e, scale)
     print(f"\n[ppo update, {cfg['enc']}/{cfg['val']}] worst per-tensor gradient error {worst:.2e}; losses {mt[:5]}")
     # forward intermediates against the float64 NumPy restatement
     import sys, os

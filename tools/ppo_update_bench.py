@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fwd-mode", type=int, default=-1, help="the intention network's forward: 0 layer by layer, 1 one fused launch (csrc/vnl_policy.hip, training form), 2 first Dense as a GEMM + the rest fused (default)")
     ap.add_argument("--fused-threads", type=int, default=0, help="threads of the fused part of the forward (256 / 512 / 1024)")
     ap.add_argument("--trajectories", type=int, default=128, help="trajectories per minibatch (128: batch_size x num_minibatches = num_envs; 1024: the reference's proportions, 8 x num_envs)")
+    ap.add_argument("--no-wgrad-transpose", action="store_true", help="large minibatches: weight gradients in the transposed-operand form (no [X | 1]' arena)")
     ap.add_argument("--noprio", action="store_true", help="no raised wave priority for the intention network's GEMMs")
     a = ap.parse_args()
     from vnl_brax_imitation_amd.ppo_imitation import hip_update, intention_losses, running_statistics
@@ -57,6 +58,8 @@ def main():
             assert upd.lib.vnl_ppo_update_tune(upd.h, -10 - a.fwd_mode, 0) == 0
         if a.fused_threads:
             assert upd.lib.vnl_ppo_update_tune(upd.h, -a.fused_threads, 0) == 0
+        if a.no_wgrad_transpose:
+            assert upd.lib.vnl_ppo_update_tune(upd.h, -6, 0) == 0
         if a.noprio:
             assert upd.lib.vnl_ppo_update_tune(upd.h, -2, 0) == 0
 

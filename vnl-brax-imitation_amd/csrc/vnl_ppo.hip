@@ -369,11 +369,21 @@ struct SlabPool {  // host-side bump allocator over the slab buffer + the list o
   ReduceJobs jobs;
   int tile;  // 0: by shape, 64 / 128: forced (tuning knob of tools/ppo_update_bench.py)
   int wg_target = 256;
+  // large minibatches (rows > 4096): the weight gradients take [X | 1]' from this arena (transpose_ones_kernel) instead of
+  // reading X transposed on the fly; `done` remembers what a step has transposed already (the two latent heads share an input)
+  float* tarena = nullptr;
+  size_t tcap = 0, tused = 0;
+  int ldt = 0, ndone = 0;
+  const float* done_src[16];
+  float* done_xt[16];
 };
 
-static void launch_wgrad_group(hipStream_t st, GemmGroup& grp) {
+__global__ void __launch_bounds__(256) transpose_ones_kernel(const float* X, int ldx, int rows, int cols, float* XT, int ldt);
+
+static void launch_wgrad_group(hipStream_t st, GemmGroup& grp, bool nn = false) {
   if (grp.n == 0) return;
-  hipLaunchKernelGGL((gemm_group_kernel<64, 64, true, false, EPI_NONE>), dim3(grp.first[grp.n]), dim3(256), 0, st, grp);
+  if (nn) hipLaunchKernelGGL((gemm_group_kernel<64, 64, false, false, EPI_NONE>), dim3(grp.first[grp.n]), dim3(256), 0, st, grp);
+  else hipLaunchKernelGGL((gemm_group_kernel<64, 64, true, false, EPI_NONE>), dim3(grp.first[grp.n]), dim3(256), 0, st, grp);
   grp.n = 0;
 }
 
@@ -382,8 +392,10 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
   SlabPool* pool;
   GemmGroup* group = nullptr;  // non-null: 64 x 64 weight gradients are collected here and launched together by flush()
   int prio = 0;
+  GemmGroup* group_nn = nullptr;  // .. and the ones that take a transposed input from the pool's arena
   void flush() {
     if (group) launch_wgrad_group(st, *group);
+    if (group_nn) launch_wgrad_group(st, *group_nn, true);
   }
   void run(bool TA, bool TB, int epi, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
            const float* bias = nullptr, const float* aux = nullptr, int ldaux = 0, float* zout = nullptr, int accumulate = 0) {
@@ -401,7 +413,24 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
   void wgrad(const float* X, int ldx, const float* dZ, int lddz, float* dW, float* db, int in, int out, int rows) {
     const int M = in + 1, N = out, K = rows;
     GemmArgs g{X, dZ, dW, nullptr, nullptr, nullptr, db, M, N, K, ldx, lddz, N, 0, K, 0, 0, 0, 1, 1, prio, 0};
-    g.vecA = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
+    // large minibatch: [X | 1]' materialised once (k-contiguous first operand), then the plain product
+    bool tr = false;
+    // (wide layers only: measured at 20,480 rows, the 1024 x 1024 layer gains 25 % this way -- 2.82 against 2.98 ms per step --
+    // while the intention network's narrow ones lose: all layers transposed 2.88 ms ..
+    // .. and from 8,192 rows on: 5,120 rows 0.88 against 0.85 ms, 10,240 rows 1.53 / 1.54, 20,480 rows 2.81 / 2.97)
+    if (pool->tarena && rows > 8192 && in >= 512 && out >= 512 && (size_t)M * pool->ldt <= pool->tcap - pool->tused) {
+      float* xt = nullptr;
+      for (int k = 0; k < pool->ndone; k++)
+        if (pool->done_src[k] == X) xt = pool->done_xt[k];
+      if (!xt && pool->ndone < 16) {
+        xt = pool->tarena + pool->tused;
+        pool->tused += (size_t)M * pool->ldt;
+        hipLaunchKernelGGL(transpose_ones_kernel, dim3((rows + 31) / 32, (in + 31) / 32), dim3(256), 0, st, X, ldx, rows, in, xt, pool->ldt);
+        pool->done_src[pool->ndone] = X, pool->done_xt[pool->ndone] = xt, pool->ndone++;
+      }
+      if (xt) g.A = xt, g.lda = pool->ldt, g.ones_row = 1, tr = true;
+    }
+    g.vecA = tr ? true : (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
     g.vecB = (lddz % 4 == 0) && (((uintptr_t)dZ) % 16 == 0);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int max_splits = K / 256 > 16 ? 16 : (K / 256 < 1 ? 1 : K / 256);  // slabs at least 256 deep
@@ -423,20 +452,42 @@ struct Gemm {  // C[M][N] (+)= op(A) op(B) with fused epilogue on stream `st`
       g.k_chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
       pool->used += splits * tot;
     }
-    if (big) {
+    GemmGroup* grp = tr ? group_nn : group;
+    if (big && !tr) {
       launch_gemm_cfg<128, 128>(st, true, false, EPI_NONE, g, splits);
-    } else if (group) {
-      if (group->n == VNL_MAX_GROUP) flush();
-      const int j = group->n++;
-      if (j == 0) group->first[0] = 0;
-      group->gx[j] = (N + 63) / 64, group->gy[j] = (M + 63) / 64;
-      group->first[j + 1] = group->first[j] + group->gx[j] * group->gy[j] * splits;
-      group->g[j] = g;
+    } else if (grp) {
+      if (grp->n == VNL_MAX_GROUP) flush();
+      const int j = grp->n++;
+      if (j == 0) grp->first[0] = 0;
+      grp->gx[j] = (N + 63) / 64, grp->gy[j] = (M + 63) / 64;
+      grp->first[j + 1] = grp->first[j] + grp->gx[j] * grp->gy[j] * splits;
+      grp->g[j] = g;
     } else {
-      launch_gemm_cfg<64, 64>(st, true, false, EPI_NONE, g, splits);
+      launch_gemm_cfg<64, 64>(st, !tr, false, EPI_NONE, g, splits);
     }
   }
 };
+
+// XT[c][r] = X[r][c] (c < cols, r < rows), XT[cols][r] = 1: a layer's input with the SAMPLE index contiguous (+ the row of ones
+// that carries the bias gradient), so that the layer's weight gradient [X | 1]' dZ runs as a product whose first operand is
+// k-contiguous -- the form with vector LDS traffic (74-78 TFLOP/s at 20,480 rows against 53 for the transposed-operand form)
+__global__ void __launch_bounds__(256) transpose_ones_kernel(const float* X, int ldx, int rows, int cols, float* XT, int ldt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < rows && c < cols) ? X[(size_t)r * ldx + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < cols && r < rows) XT[(size_t)c * ldt + r] = tile[tx][ty + 8 * k];
+  }
+  if (blockIdx.y == 0 && ty == 0 && r0 + tx < rows) XT[(size_t)cols * ldt + r0 + tx] = 1.f;
+}
 
 // ------------------------------------------------------------------------------------------------ small kernels
 // observation normalisation (running_statistics.normalize) for the T*B rows + the B bootstrap rows, and the trajectory
@@ -730,6 +781,10 @@ struct vnl_ppo_update {
   int tile = 0, wg_target = 512;  // (wg_target: workgroups a split-K weight gradient is split up to; 512 measured best)
   size_t slab_floats = 0, slab_floats_p = 0, part_floats = 0;  // (slab_floats_p: the intention network's share, at the end)
   std::vector<float*> encH, encY, encS, decH, decY, decS, valZ, valA;
+  float* tarena = nullptr;  // transposed layer inputs of a large minibatch's weight gradients (SlabPool::tarena): value part | policy part
+  size_t tarena_v = 0, tarena_p = 0;
+  int ldt = 0;
+  bool wgrad_t = true;      // tuning knob (tile = -6 switches it off)
   vnl_policy* fused = nullptr;  // the intention network's forward pass as ONE launch (csrc/vnl_policy.hip in its training form);
                                 // null: the network is outside that kernel's limits -> layer by layer
   int fwd_mode = 2;  // the intention network's forward: 0 layer by layer, 1 ONE fused launch, 2 first Dense as a GEMM + the rest fused
@@ -764,6 +819,10 @@ extern "C" int vnl_ppo_update_tune(vnl_ppo_update* u, int tile, int wg_target) {
   }
   if (u && (tile == -256 || tile == -512 || tile == -1024)) {  // threads of the fused part of the intention network's forward
     return u->fused ? vnl_policy_set_threads2_(u->fused, -tile) : VNL_OK;
+  }
+  if (u && tile == -6) {
+    u->wgrad_t = false;
+    return VNL_OK;
   }
   if (u && tile == -2) {
     u->prio = 0;
@@ -890,6 +949,17 @@ extern "C" int vnl_ppo_update_create(const vnl_ppo_net_spec* sp, int32_t T, int3
     AL(a, Nv * u->val[i].out);
     u->valZ.push_back(z), u->valA.push_back(a);
   }
+  if (N > 8192) {  // (the reference's own proportions: 20,480 rows; at the 2,560 rows of the primary config the arena is not used)
+    u->ldt = (int)((N + 3) & ~(size_t)3);
+    size_t rows_v = 0, rows_p = 0;
+    for (const DenseP& d : u->val) rows_v += d.in + 1;
+    for (const DenseP& d : u->enc) rows_p += d.in + 1;
+    for (const DenseP& d : u->dec) rows_p += d.in + 1;
+    rows_p += u->enc.back().out + 1;       // the latent heads' shared input
+    rows_p += u->val.back().in + 1;        // the value head's gradient rides with the intention network's group
+    u->tarena_v = rows_v * u->ldt, u->tarena_p = rows_p * u->ldt;
+    AL(u->tarena, u->tarena_v + u->tarena_p);
+  }
   // split-K slabs of every weight gradient of a step (wgrad falls back to one slab) + the LayerNorm backward's per-block
   // partial sums (80 blocks x 2 h each)
   u->slab_floats_p = 8 * u->n_policy + 4096 + (size_t)80 * 2 * wmax * (u->enc.size() + u->dec.size());
@@ -993,9 +1063,13 @@ extern "C" int vnl_ppo_minibatch_grad_part(vnl_ppo_update* u, const float* param
   pool.jobs.njobs = 0, pool.jobs.start4[0] = 0, pool.jobs.prio = 0;
   poolP.jobs.njobs = 0, poolP.jobs.start4[0] = 0, poolP.jobs.prio = u->prio;
   pool.wg_target = poolP.wg_target = u->wg_target;
-  GemmGroup group;
-  group.n = 0;
-  Gemm GV{st, &pool}, GP{sp2, &poolP, &group, u->prio};
+  if (u->tarena && u->wgrad_t) {
+    pool.tarena = u->tarena, pool.tcap = u->tarena_v, pool.ldt = u->ldt;
+    poolP.tarena = u->tarena + u->tarena_v, poolP.tcap = u->tarena_p, poolP.ldt = u->ldt;
+  }
+  GemmGroup group, group_nn;
+  group.n = 0, group_nn.n = 0;
+  Gemm GV{st, &pool}, GP{sp2, &poolP, &group, u->prio, &group_nn};
   auto reduce_pool = [](SlabPool& pl, hipStream_t s) {
     if (pl.jobs.njobs == 0) return;
     const unsigned total4 = pl.jobs.start4[pl.jobs.njobs];
