@@ -182,6 +182,13 @@ static bool fuse_welded_bodies(const vnl_model& in, vnl_model* out, FuseMap* fm)
   int nd = 0;
   for (int b = 0; b < nb; b++) {
     keep[b] = (b < 2 || jn[b] > 0) ? 1 : 0;
+    // (a jointless body hanging off the world -- directly or through other jointless bodies -- is NOT folded: such a model is
+    // not a single tree rooted at body 1 and is rejected below, as it always was)
+    if (!keep[b]) {
+      int a = bp[b];
+      while (a > 1 && !keep[a]) a = bp[a];
+      if (a == 0) keep[b] = 1;
+    }
     nd += keep[b];
   }
   fm->nb_out = nb;
